@@ -1,0 +1,168 @@
+/*
+ * stmpc.h -- C-ABI of the MI355X-native ST ("MPC") lattice solver.
+ *
+ * This is the drop-in boundary for the reference's trajectory-search hot path.
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference checkout jlubars/RL-MPC-LaneMerging):
+ *
+ *   stmpc_solve_grid          <- st_cy.solve_s_t_path_fast           st_cy.pyx:315-399 (call site st.py:740-746)
+ *   stmpc_build_grid          <- st.find_s_t_obstacles_from_state    st.py:25-70
+ *   stmpc_solve_batch[_device]<- st.get_appropriate_base_st_path_and_obstacles (st.py:726-754) applied to N
+ *                                independent HighwayState's (prediction.py:9-20), plus the path-distance probe of
+ *                                st.test_guaranteed_crash_from_state (st.py:790-802)
+ *   stmpc_predict_batch       <- HighwayState.predict_step_with_ego / predict_step_without_ego (prediction.py:22-105)
+ *   stmpc_ego_s               <- control.get_ego_s                   control.py:373-380
+ *   stmpc_num_s / stmpc_num_t <- the np.arange sizes at st.py:31-32
+ *
+ * Plain pointers and sizes only; no torch / numpy types.  All floating point is
+ * IEEE fp64.  Functions return 0 on success or a negative STMPC_E* code;
+ * stmpc_last_error() returns a thread-local message for the last failure.
+ * The library has no CPU fallback: without a HIP device every compute entry
+ * returns STMPC_ENODEV.
+ */
+#ifndef STMPC_H
+#define STMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STMPC_OK        0
+#define STMPC_EINVAL   -1   /* bad argument (NULL, size, Kmax/H/S out of range) */
+#define STMPC_ENODEV   -2   /* no HIP device / device init failed */
+#define STMPC_EHIP     -3   /* a HIP runtime call failed (message has hipGetErrorString) */
+#define STMPC_ENOMEM   -4   /* device allocation failed */
+#define STMPC_EINTERNAL -5  /* solver reported an impossible state (should not happen) */
+
+#define STMPC_KMAX_LIMIT 32   /* max other vehicles per state */
+#define STMPC_H_LIMIT    64   /* max time layers */
+#define STMPC_S_LIMIT    65000 /* max position cells (back-pointers are 16-bit) */
+
+/* Settings.* that parameterise the path (config.py:30-37,94-110,143,150).  Field
+ * order = st.py:727-734 (grid) then the 11 tunables in st_cy.solve_s_t_path_fast's
+ * positional order (st.py:740-746) then grid/predictor constants. */
+typedef struct stmpc_params {
+    double future_s;        /* Settings.FUTURE_S */
+    double ds;              /* Settings.S_DISCRETIZATION */
+    double dt;              /* Settings.T_DISCRETIZATION */
+    double future_t;        /* Settings.FUTURE_T */
+    double start_unc;       /* Settings.START_UNCERTAINTY */
+    double unc_per_s;       /* Settings.UNCERTAINTY_PER_SECOND */
+    double d_w, v_w, a_w, j_w;      /* D/V/A/J_WEIGHT */
+    double v_des;           /* DESIRED_SPEED */
+    double v_max;           /* MAX_SPEED */
+    double a_min, a_max;    /* MAX_NEGATIVE_ACCELERATION, MAX_POSITIVE_ACCELERATION */
+    double j_min, j_max;    /* MINIMUM_NEGATIVE_JERK, MAXIMUM_POSITIVE_JERK */
+    double min_allowed;     /* MIN_ALLOWED_DISTANCE */
+    double car_length;      /* CAR_LENGTH */
+    double crash_min_s;     /* CRASH_MIN_S */
+    double max_pred_decel;  /* MAX_PREDICTED_DECELERATION */
+    double follow_gap;      /* literal 30 at prediction.py:85 */
+    double react_thr;       /* HighwayState.ego_reaction_threshold (prediction.py:11) */
+    double crash_thr;       /* HighwayState.ego_crash_threshold (prediction.py:12) */
+    double comb_min_dist;   /* COMBINATION_MIN_DISTANCE */
+} stmpc_params;
+
+/* Per-launch solver statistics (filled by stmpc_get_stats after a batch solve). */
+typedef struct stmpc_stats {
+    int64_t episodes;        /* N of the last batch */
+    int64_t fast_path;       /* episodes finished by the LDS-resident kernel */
+    int64_t fallback;        /* episodes re-solved by the HBM-scratch kernel (window overflow) */
+    int64_t retries;         /* bound-tightening retries inside the fast kernel */
+    double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
+    double  dp_kernel_ms;    /* device time of the lattice DP kernel alone */
+} stmpc_stats;
+
+typedef struct stmpc_ctx stmpc_ctx;
+
+/* Library / device identification, e.g. "stmpc 0.1 hip gfx950 AMD Instinct MI355X cu=256". */
+const char *stmpc_backend_info(void);
+const char *stmpc_last_error(void);
+
+/* Context = one HIP device + its staging/scratch buffers.  device < 0 -> current device. */
+int  stmpc_create(stmpc_ctx **out, int device);
+void stmpc_destroy(stmpc_ctx *ctx);
+
+/* Host-side exact helpers (same libm calls as the reference's Python). */
+double stmpc_ego_s(double x, double y);                               /* control.py:373-380 */
+int    stmpc_num_s(const stmpc_params *p, double start_s);            /* len(np.arange(...)) st.py:31 */
+int    stmpc_num_t(const stmpc_params *p);                            /* len(np.arange(...)) st.py:32 */
+double stmpc_path_mean_abs_jerk(const double *s_sequence, int n, double v0, double a0, double dt); /* st.py:274-288 */
+
+/*
+ * Batched solve, DEVICE pointers (the hot path; inputs already resident in HBM).
+ *   ego      [N][5]     x, y, speed, acceleration, start_s (= get_ego_s(x,y), see stmpc_ego_s)
+ *   k_count  [N]        number of other vehicles of each state (<= Kmax), front->back order
+ *   other_x  [N][Kmax]  other_xs   (prediction.py:138-141 ordering), entries >= k_count ignored
+ *   other_v  [N][Kmax]  other_speeds
+ * outputs (any of path_dist / crash may be NULL):
+ *   path_idx [N][H]     s index per layer, -1 past best_t   (s_sequence[t] = s_values[path_idx[t]], 0.0 past best_t)
+ *   best_t   [N]        deepest layer reached (H-1 = success)            st_cy.pyx:365-369
+ *   cost     [N]        accumulated cost of the terminal node (dropped by the reference at st_cy.pyx:393-399)
+ *   path_dist[N][H]     distances[t, int((s_t - s_0)/delta_s)] along the path, NaN past best_t   st.py:797-799
+ *   crash    [N]        st.test_guaranteed_crash_from_state's verdict    st.py:790-802
+ * stream is a hipStream_t (NULL = default stream).  Asynchronous w.r.t. the host.
+ */
+int stmpc_solve_batch_device(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
+                             const double *d_ego, const int32_t *d_k_count,
+                             const double *d_other_x, const double *d_other_v,
+                             int32_t *d_path_idx, int32_t *d_best_t, double *d_cost,
+                             double *d_path_dist, int32_t *d_crash, void *stream);
+
+/* Same with HOST pointers: stages H2D, solves, copies back, synchronises. */
+int stmpc_solve_batch(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
+                      const double *ego, const int32_t *k_count,
+                      const double *other_x, const double *other_v,
+                      int32_t *path_idx, int32_t *best_t, double *cost,
+                      double *path_dist, int32_t *crash);
+
+int stmpc_get_stats(stmpc_ctx *ctx, stmpc_stats *out);
+
+/*
+ * Single-episode entry with materialised grids: st_cy.solve_s_t_path_fast's exact
+ * argument meaning (st_cy.pyx:315).  HOST pointers.  obstacles [H][S] bytes
+ * (non-zero = blocked), distances [H][S], s_values [S], t_values [H];
+ * s_sequence_out [H] receives s along the path, 0.0 past the deepest layer reached.
+ * Requires H >= 2, S >= 2 (the reference reads s_values[1], t_indices[1] unconditionally).
+ */
+int stmpc_solve_grid(stmpc_ctx *ctx, const uint8_t *obstacles, const double *s_values, int S,
+                     const double *t_values, int H, double ego_start_speed,
+                     double ego_start_acceleration, const double *distances,
+                     double d_weight, double v_weight, double a_weight, double j_weight,
+                     double desired_speed, double max_speed, double negative_acceleration_limit,
+                     double positive_acceleration_limit, double negative_jerk_limit,
+                     double positive_jerk_limit, double min_allowed_distance,
+                     double *s_sequence_out);
+
+/*
+ * st.find_s_t_obstacles_from_state for one state (HOST pointers): fills
+ * obstacles [H][S] (0/1), distances [H][S], s_values [S], t_values [H] with
+ * S = stmpc_num_s(p, start_s), H = stmpc_num_t(p).  state5 = x, y, v, a, start_s.
+ */
+int stmpc_build_grid(stmpc_ctx *ctx, const stmpc_params *p, const double *state5, int k,
+                     const double *other_x, const double *other_v,
+                     uint8_t *obstacles, double *distances, double *s_values, double *t_values);
+
+/*
+ * Batched one-step traffic prediction (HOST pointers), prediction.py:22-105.
+ *   mode 0: predict_step_with_ego(selected_speed[i], dt, min_crash_distance)
+ *   mode 1: predict_step_without_ego(dt, min_crash_distance)   (selected_speed ignored, may be NULL)
+ * state layout as in stmpc_solve_batch but ego is [N][4] = x, y, v, a.  Outputs have the same
+ * shapes; crashed [N] receives the crash flag.
+ */
+int stmpc_predict_batch(stmpc_ctx *ctx, const stmpc_params *p, int mode, int N, int Kmax,
+                        const double *ego4, const int32_t *k_count, const double *other_x,
+                        const double *other_v, const double *selected_speed, double dt,
+                        double min_crash_distance, double *ego4_out, double *other_x_out,
+                        double *other_v_out, int32_t *crashed);
+
+/* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
+ * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b) HOST pointers. */
+int stmpc_probe_arith(stmpc_ctx *ctx, int op, const double *a, const double *b, double *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STMPC_H */

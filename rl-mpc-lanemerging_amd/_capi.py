@@ -1,0 +1,252 @@
+"""ctypes binding of the C-ABI declared in ``include/stmpc.h``.
+
+This is the whole Python<->native boundary: plain pointers and sizes.  There is no CPU
+fallback -- if ``libstmpc.so`` is missing the import of this module raises, and if no GPU
+is visible ``Context()`` raises ``StmpcError(STMPC_ENODEV)``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+STMPC_OK, STMPC_EINVAL, STMPC_ENODEV, STMPC_EHIP, STMPC_ENOMEM, STMPC_EINTERNAL = 0, -1, -2, -3, -4, -5
+KMAX_LIMIT, H_LIMIT, S_LIMIT = 32, 64, 65000
+
+
+class StmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("stmpc error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """``stmpc_params`` (include/stmpc.h)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "future_s", "ds", "dt", "future_t", "start_unc", "unc_per_s",
+        "d_w", "v_w", "a_w", "j_w", "v_des", "v_max", "a_min", "a_max", "j_min", "j_max", "min_allowed",
+        "car_length", "crash_min_s", "max_pred_decel", "follow_gap", "react_thr", "crash_thr", "comb_min_dist")]
+
+    @classmethod
+    def from_settings(cls, S):
+        """Read the flags exactly where the reference reads them (st.py:727-746, 37, 46, 800;
+        prediction.py:11-12, 85-86)."""
+        return cls(
+            future_s=S.FUTURE_S, ds=S.S_DISCRETIZATION, dt=S.T_DISCRETIZATION, future_t=S.FUTURE_T,
+            start_unc=S.START_UNCERTAINTY, unc_per_s=S.UNCERTAINTY_PER_SECOND,
+            d_w=S.D_WEIGHT, v_w=S.V_WEIGHT, a_w=S.A_WEIGHT, j_w=S.J_WEIGHT, v_des=S.DESIRED_SPEED,
+            v_max=S.MAX_SPEED, a_min=S.MAX_NEGATIVE_ACCELERATION, a_max=S.MAX_POSITIVE_ACCELERATION,
+            j_min=S.MINIMUM_NEGATIVE_JERK, j_max=S.MAXIMUM_POSITIVE_JERK, min_allowed=S.MIN_ALLOWED_DISTANCE,
+            car_length=S.CAR_LENGTH, crash_min_s=S.CRASH_MIN_S, max_pred_decel=S.MAX_PREDICTED_DECELERATION,
+            follow_gap=30.0, react_thr=8.0, crash_thr=11.0, comb_min_dist=S.COMBINATION_MIN_DISTANCE)
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [("episodes", C.c_int64), ("fast_path", C.c_int64), ("fallback", C.c_int64),
+                ("retries", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
+
+
+_lib = None
+
+EXPORTS = (
+    "stmpc_backend_info", "stmpc_last_error", "stmpc_create", "stmpc_destroy", "stmpc_ego_s", "stmpc_num_s",
+    "stmpc_num_t", "stmpc_path_mean_abs_jerk", "stmpc_solve_batch_device", "stmpc_solve_batch", "stmpc_get_stats",
+    "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith",
+)
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load ``libstmpc.so`` (must have been built in-tree: ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(this package has no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    dp, ip, u8p, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_void_p
+    pp = C.POINTER(Params)
+    lib.stmpc_backend_info.restype = C.c_char_p
+    lib.stmpc_last_error.restype = C.c_char_p
+    lib.stmpc_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.stmpc_destroy.argtypes = [vp]
+    lib.stmpc_destroy.restype = None
+    lib.stmpc_ego_s.argtypes = [C.c_double, C.c_double]
+    lib.stmpc_ego_s.restype = C.c_double
+    lib.stmpc_num_s.argtypes = [pp, C.c_double]
+    lib.stmpc_num_t.argtypes = [pp]
+    lib.stmpc_path_mean_abs_jerk.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double]
+    lib.stmpc_path_mean_abs_jerk.restype = C.c_double
+    lib.stmpc_solve_batch_device.argtypes = [vp, pp, C.c_int, C.c_int] + [vp] * 9 + [vp]
+    lib.stmpc_solve_batch.argtypes = [vp, pp, C.c_int, C.c_int, dp, ip, dp, dp, ip, ip, dp, dp, ip]
+    lib.stmpc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.stmpc_solve_grid.argtypes = [vp, u8p, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp] + [C.c_double] * 11 + [dp]
+    lib.stmpc_build_grid.argtypes = [vp, pp, dp, C.c_int, dp, dp, u8p, dp, dp, dp]
+    lib.stmpc_predict_batch.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
+                                        dp, dp, dp, ip]
+    lib.stmpc_probe_arith.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _u8ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def ego_s(x, y):
+    """control.get_ego_s evaluated by the library's host helper (same libm as CPython)."""
+    return load().stmpc_ego_s(float(x), float(y))
+
+
+def num_s(params, start_s):
+    return load().stmpc_num_s(C.byref(params), float(start_s))
+
+
+def num_t(params):
+    return load().stmpc_num_t(C.byref(params))
+
+
+def backend_info():
+    return load().stmpc_backend_info().decode()
+
+
+class Context:
+    """One HIP device + its scratch (``stmpc_ctx``)."""
+
+    def __init__(self, device=-1):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.stmpc_create(C.byref(h), int(device))
+        if rc != 0:
+            raise StmpcError(rc, self._lib.stmpc_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise StmpcError(rc, self._lib.stmpc_last_error().decode())
+
+    # -- batched solve, host numpy arrays --------------------------------------------------
+    def solve_batch(self, params, ego, k_count, other_x, other_v, want_dist=True):
+        ego = np.ascontiguousarray(ego, dtype=np.float64)
+        k_count = np.ascontiguousarray(k_count, dtype=np.int32)
+        N = ego.shape[0]
+        if ego.ndim != 2 or ego.shape[1] != 5:
+            raise ValueError("ego must be [N,5] (x, y, v, a, start_s)")
+        other_x = np.ascontiguousarray(other_x, dtype=np.float64).reshape(N, -1)
+        other_v = np.ascontiguousarray(other_v, dtype=np.float64).reshape(N, -1)
+        Kmax = other_x.shape[1]
+        H = num_t(params)
+        path = np.empty((N, H), dtype=np.int32)
+        best_t = np.empty(N, dtype=np.int32)
+        cost = np.empty(N, dtype=np.float64)
+        pdist = np.empty((N, H), dtype=np.float64) if want_dist else None
+        crash = np.empty(N, dtype=np.int32) if want_dist else None
+        self._chk(self._lib.stmpc_solve_batch(self._h, C.byref(params), N, Kmax, _dptr(ego), _iptr(k_count),
+                                              _dptr(other_x) if Kmax else None, _dptr(other_v) if Kmax else None,
+                                              _iptr(path), _iptr(best_t), _dptr(cost), _dptr(pdist), _iptr(crash)))
+        return path, best_t, cost, pdist, crash
+
+    # -- batched solve, device pointers (ints), asynchronous ---------------------------------
+    def solve_batch_device(self, params, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_pd=0, d_crash=0,
+                           stream=0):
+        self._chk(self._lib.stmpc_solve_batch_device(self._h, C.byref(params), int(N), int(Kmax), d_ego, d_k, d_ox,
+                                                     d_ov, d_path, d_bt, d_cost, d_pd or None, d_crash or None,
+                                                     stream or None))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self._lib.stmpc_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+    # -- st_cy.solve_s_t_path_fast semantics -------------------------------------------------------
+    def solve_grid(self, obstacles, s_values, t_values, v0, a0, distances, tunables11):
+        ob = np.ascontiguousarray(obstacles).view(np.uint8) if obstacles.dtype == np.bool_ else \
+            np.ascontiguousarray(obstacles, dtype=np.uint8)
+        sv = np.ascontiguousarray(s_values, dtype=np.float64)
+        tv = np.ascontiguousarray(t_values, dtype=np.float64)
+        di = np.ascontiguousarray(distances, dtype=np.float64)
+        H, S = tv.shape[0], sv.shape[0]
+        if ob.shape != (H, S) or di.shape != (H, S):
+            raise ValueError("obstacles/distances must be [num_t, num_s]")
+        out = np.empty(H, dtype=np.float64)
+        self._chk(self._lib.stmpc_solve_grid(self._h, _u8ptr(ob), _dptr(sv), S, _dptr(tv), H, float(v0), float(a0),
+                                             _dptr(di), *[float(x) for x in tunables11], _dptr(out)))
+        return out
+
+    def build_grid(self, params, state5, other_x, other_v):
+        state5 = np.ascontiguousarray(state5, dtype=np.float64)
+        ox = np.ascontiguousarray(other_x, dtype=np.float64)
+        ov = np.ascontiguousarray(other_v, dtype=np.float64)
+        k = ox.shape[0]
+        H, S = num_t(params), num_s(params, state5[4])
+        ob = np.empty((H, S), dtype=np.uint8)
+        di = np.empty((H, S), dtype=np.float64)
+        sv = np.empty(S, dtype=np.float64)
+        tv = np.empty(H, dtype=np.float64)
+        self._chk(self._lib.stmpc_build_grid(self._h, C.byref(params), _dptr(state5), k, _dptr(ox) if k else None,
+                                             _dptr(ov) if k else None, _u8ptr(ob), _dptr(di), _dptr(sv), _dptr(tv)))
+        return ob.view(np.bool_), sv, tv, di
+
+    def predict_batch(self, params, mode, ego4, k_count, other_x, other_v, selected_speed, dt, min_crash_distance):
+        ego4 = np.ascontiguousarray(ego4, dtype=np.float64)
+        N = ego4.shape[0]
+        k_count = np.ascontiguousarray(k_count, dtype=np.int32)
+        other_x = np.ascontiguousarray(other_x, dtype=np.float64).reshape(N, -1)
+        other_v = np.ascontiguousarray(other_v, dtype=np.float64).reshape(N, -1)
+        Kmax = other_x.shape[1]
+        sel = np.ascontiguousarray(selected_speed, dtype=np.float64) if selected_speed is not None else None
+        eo = np.empty_like(ego4)
+        xo = np.array(other_x, copy=True)
+        vo = np.array(other_v, copy=True)
+        cr = np.empty(N, dtype=np.int32)
+        self._chk(self._lib.stmpc_predict_batch(self._h, C.byref(params), int(mode), N, Kmax, _dptr(ego4), _iptr(k_count),
+                                                _dptr(other_x) if Kmax else None, _dptr(other_v) if Kmax else None,
+                                                _dptr(sel), float(dt), float(min_crash_distance), _dptr(eo),
+                                                _dptr(xo) if Kmax else None, _dptr(vo) if Kmax else None, _iptr(cr)))
+        return eo, xo, vo, cr
+
+    def probe_arith(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+        out = np.empty_like(a)
+        self._chk(self._lib.stmpc_probe_arith(self._h, int(op), _dptr(a), _dptr(b), _dptr(out), a.size))
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the current HIP device (created on first use)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(-1)
+    return _default_ctx

@@ -1,0 +1,116 @@
+"""Solver-relevant flags of the reference's global ``Settings`` class.
+
+Mirrors ``config.py:7-170`` of the reference for exactly the attributes that reach the
+ST ("MPC") hot path (``config.py:30-37, 94-110, 143, 145-154``); everything else in the
+reference's ``Settings`` (RL training, logging, SUMO) is outside this package's scope.
+``load_from_file`` keeps the reference's semantics (``config.py:161-170``): every key of
+the JSON file is set as a class attribute, so the shipped experiment configs
+(``configs/*.json``) load unchanged.
+"""
+import inspect
+import json
+
+
+class Settings:
+    # Simulation (config.py:30-37)
+    TICK_LENGTH = 0.2
+    MAX_POSITIVE_ACCELERATION = 4.5
+    MAX_NEGATIVE_ACCELERATION = -6.0
+    MINIMUM_NEGATIVE_JERK = -5.0
+    MAXIMUM_POSITIVE_JERK = 5.0
+    MAX_SPEED = 30
+    CAR_LENGTH = 5.0
+
+    # S-T solver and continuous reward (config.py:94)
+    DESIRED_SPEED = 30.0
+
+    # S-T solver (config.py:97-110)
+    USE_CYTHON = True            # kept for config compatibility; this package always runs the HIP solver
+    USE_FAST_ST_SOLVER = True
+    S_DISCRETIZATION = 0.05
+    T_DISCRETIZATION = 0.30
+    FUTURE_S = 150.0
+    FUTURE_T = 5.0
+    START_UNCERTAINTY = 0.0
+    UNCERTAINTY_PER_SECOND = 0.0
+    V_WEIGHT = 0.5
+    A_WEIGHT = 10.0
+    J_WEIGHT = 10.0
+    D_WEIGHT = 10.0
+    MIN_ALLOWED_DISTANCE = 5
+    CRASH_MIN_S = 12
+
+    # Prediction (config.py:143)
+    MAX_PREDICTED_DECELERATION = -4
+
+    # Combined controller (config.py:146-155)
+    ROLLOUT_LENGTH = 5
+    ST_TEST_ROLLOUTS = 5
+    TEST_ST_STRICTLY_BETTER = True
+    TEST_ROLLOUT_STATE = True
+    CHECK_ROLLOUT_CRASH = True
+    COMBINATION_MIN_DISTANCE = 5.1
+    STOP_X = 65
+
+    @classmethod
+    def export_settings(cls):
+        return {x[0]: x[1] for x in inspect.getmembers(cls, lambda m: not inspect.isroutine(m))
+                if not x[0].startswith('__')}
+
+    @classmethod
+    def load_from_file(cls, filename):
+        with open(filename, 'rb') as file:
+            contents = json.load(file)
+        for item in contents:
+            value = contents[item]
+            if isinstance(value, dict):
+                value = {int(x): value[x] for x in value}
+            setattr(cls, item, value)
+
+    @classmethod
+    def snapshot(cls):
+        """Copy of the current solver flags (used by tests to restore state)."""
+        return dict(cls.export_settings())
+
+    @classmethod
+    def restore(cls, snap):
+        for k, v in snap.items():
+            setattr(cls, k, v)
+
+
+#: The synthetic benchmark point of BASELINE.json (H=40, A=21, K=6), mapped onto the
+#: reference's parameters as SURVEY.md section 8(d) prescribes: 40 time layers of 0.3 s,
+#: FUTURE_S = 360 m (S = 7201 cells), an acceleration-limited window of
+#: (a_max - a_min) * dt^2 / ds = 20.16 cells (fan-out 20-21) with non-binding jerk limits.
+SYNTHETIC_H40A21 = {
+    "T_DISCRETIZATION": 0.30,
+    "FUTURE_T": 11.7,
+    "S_DISCRETIZATION": 0.05,
+    "FUTURE_S": 360.0,
+    "MAX_POSITIVE_ACCELERATION": 5.2,
+    "MAX_NEGATIVE_ACCELERATION": -6.0,
+    "MINIMUM_NEGATIVE_JERK": -35.0,
+    "MAXIMUM_POSITIVE_JERK": 35.0,
+    "MAX_SPEED": 30,
+    "DESIRED_SPEED": 30.0,
+    "V_WEIGHT": 0.5, "A_WEIGHT": 10.0, "J_WEIGHT": 10.0, "D_WEIGHT": 10.0,
+    "MIN_ALLOWED_DISTANCE": 5, "CRASH_MIN_S": 20,
+    "START_UNCERTAINTY": 0.0, "UNCERTAINTY_PER_SECOND": 0.0,
+}
+
+#: Solver parameters shared by all 86 shipped configs (e.g. configs/st_low.json:14-25).
+REFERENCE_DEFAULT = {
+    "S_DISCRETIZATION": 0.05, "T_DISCRETIZATION": 0.30, "FUTURE_S": 150.0, "FUTURE_T": 5.0,
+    "START_UNCERTAINTY": 0.0, "UNCERTAINTY_PER_SECOND": 0.0,
+    "V_WEIGHT": 0.5, "A_WEIGHT": 10.0, "J_WEIGHT": 10.0, "D_WEIGHT": 10.0,
+    "MIN_ALLOWED_DISTANCE": 5, "CRASH_MIN_S": 20,
+    "MAX_POSITIVE_ACCELERATION": 4.5, "MAX_NEGATIVE_ACCELERATION": -6.0,
+    "MINIMUM_NEGATIVE_JERK": -5.0, "MAXIMUM_POSITIVE_JERK": 5.0,
+    "MAX_SPEED": 30, "DESIRED_SPEED": 30.0,
+}
+
+
+def apply_overrides(overrides):
+    """Set ``Settings`` attributes from a dict (same effect as ``load_from_file`` on a JSON)."""
+    for k, v in overrides.items():
+        setattr(Settings, k, v)

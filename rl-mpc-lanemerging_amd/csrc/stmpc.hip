@@ -1,0 +1,523 @@
+// stmpc.hip -- C-ABI (include/stmpc.h) over the gfx950 kernels in stmpc_kernels.hpp.
+// Host side: context, device buffers, launch sequencing on the caller's HIP stream.
+// No CPU fallback: every compute entry needs a HIP device.
+#include "stmpc_kernels.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "stmpc.h"
+
+using namespace stmpc;
+
+namespace {
+
+thread_local std::string g_err;
+std::string g_info;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? STMPC_ENOMEM : STMPC_EHIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+    } while (0)
+
+// libm pow through a volatile pointer so clang cannot fold pow(x,2.0)/pow(x,3.0): the reference's
+// Python evaluates float**int with libm pow (control.py:38) and Cython's dt**3 likewise (st_cy.pyx:49).
+double (*volatile host_pow)(double, double) = pow;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return STMPC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(STMPC_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        cap = want;
+        return STMPC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+int next_pow2(int v) { int w = 1; while (w < v) w <<= 1; return w; }
+
+}  // namespace
+
+struct stmpc_ctx {
+    int device = 0;
+    int num_cu = 256;
+    int lds_per_block = 65536;
+    // scratch
+    DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, overflow, bp, gscratch, bp_fb;
+    // staging for the host-pointer API
+    DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    stmpc_stats stats{};
+    bool stats_pending = false;
+    int fast_W = 1024;          // LDS window (cells) of the fast tier
+    int fast_blocks_per_cu = 5;
+};
+
+extern "C" {
+
+const char *stmpc_last_error(void) { return g_err.c_str(); }
+
+const char *stmpc_backend_info(void) {
+    if (!g_info.empty()) return g_info.c_str();
+    int n = 0;
+    char buf[512];
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        g_info = "stmpc 0.1 hip (no device)";
+        return g_info.c_str();
+    }
+    hipDeviceProp_t pr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { g_info = "stmpc 0.1 hip (device query failed)"; return g_info.c_str(); }
+    snprintf(buf, sizeof buf, "stmpc 0.1 hip %s %s cu=%d lds=%zu devices=%d", pr.gcnArchName, pr.name,
+             pr.multiProcessorCount, (size_t)pr.sharedMemPerBlock, n);
+    g_info = buf;
+    return g_info.c_str();
+}
+
+int stmpc_create(stmpc_ctx **out, int device) {
+    if (!out) return fail(STMPC_EINVAL, "stmpc_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(STMPC_ENODEV, "no HIP device available (stmpc has no CPU fallback)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(STMPC_ENODEV, "hipGetDevice failed"); }
+    if (device >= n) return fail(STMPC_EINVAL, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    stmpc_ctx *c = new stmpc_ctx();
+    c->device = device;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) == hipSuccess) {
+        c->num_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        c->lds_per_block = (int)pr.sharedMemPerBlock;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) {
+        delete c;
+        return fail(STMPC_EHIP, "hipEventCreate failed");
+    }
+    const char *w = getenv("STMPC_FAST_W");
+    if (w) { int v = atoi(w); if (v >= 64 && v <= 4096 && (v & (v - 1)) == 0) c->fast_W = v; }
+    *out = c;
+    return STMPC_OK;
+}
+
+void stmpc_destroy(stmpc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->overflow, &c->bp,
+                     &c->gscratch, &c->bp_fb, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
+                     &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3};
+    for (DevBuf *b : all) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
+    delete c;
+}
+
+// ---- host helpers ------------------------------------------------------------------------
+double stmpc_ego_s(double x, double y) {
+    // control.py:366-380 with control.distance (control.py:37-38): math.sqrt(dx**2 + dy**2)
+    const double mpx = -50.9, mpy = 1.72, mp2x = 1.5, mp3x = -51.0;
+    const double common_s = mp2x - mp3x;
+    if (x < mpx) return -sqrt(host_pow(x - mpx, 2.0) + host_pow(y - mpy, 2.0));
+    else if (x < mp2x) return sqrt(host_pow(x - mpx, 2.0) + host_pow(y - mpy, 2.0));
+    else return x - mp2x + common_s;
+}
+
+int stmpc_num_s(const stmpc_params *p, double start_s) {
+    if (!p) return STMPC_EINVAL;
+    double stop = start_s + p->future_s + p->ds;
+    return (int)ceil((stop - start_s) / p->ds);
+}
+
+int stmpc_num_t(const stmpc_params *p) {
+    if (!p) return STMPC_EINVAL;
+    double stop = p->future_t + p->dt;
+    return (int)ceil((stop - 0.0) / p->dt);
+}
+
+double stmpc_path_mean_abs_jerk(const double *s, int n, double v0, double a0, double dt) {
+    // st.py:274-288
+    double prev_a = a0, prev_v = v0, acc = 0.0;
+    for (int i = 1; i < n; ++i) {
+        double v = (s[i] - s[i - 1]) / dt;
+        double a = (v - prev_v) / dt;
+        double j = (a - prev_a) / dt;
+        prev_v = v; prev_a = a;
+        acc += fabs(j);
+    }
+    return acc / (double)(n - 1);
+}
+
+}  // extern "C"
+
+namespace {
+
+// np.arange(0, future_t + dt, dt) as numpy fills it (st.py:32)
+void host_t_values(const stmpc_params *p, int H, double *t) {
+    if (H > 0) t[0] = 0.0;
+    if (H > 1) t[1] = 0.0 + p->dt;
+    if (H > 2) { double d = t[1] - t[0]; for (int i = 2; i < H; ++i) t[i] = 0.0 + (double)i * d; }
+}
+
+int make_devp(const stmpc_params *p, DevP *d) {
+    if (!p) return fail(STMPC_EINVAL, "params is NULL");
+    if (!(p->ds > 0) || !(p->dt > 0)) return fail(STMPC_EINVAL, "ds and dt must be positive");
+    int H = stmpc_num_t(p);
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "number of time layers must be in [2, 64]");
+    memset(d, 0, sizeof *d);
+    d->future_s = p->future_s; d->ds = p->ds;
+    double tv[STMPC_MAXH];
+    host_t_values(p, H, tv);
+    d->dt = tv[1] - tv[0];                       // st_cy.pyx:319 delta_t = t_indices[1] - t_indices[0]
+    d->dt2 = d->dt * d->dt;                      // delta_t**2 (compiled to x*x)
+    d->dt3 = host_pow(d->dt, 3.0);               // delta_t**3 -> libm pow
+    d->d_w = p->d_w; d->v_w = p->v_w; d->a_w = p->a_w; d->j_w = p->j_w; d->v_des = p->v_des; d->v_max = p->v_max;
+    d->a_min = p->a_min; d->a_max = p->a_max; d->j_min = p->j_min; d->j_max = p->j_max; d->min_allowed = p->min_allowed;
+    d->car_length = p->car_length;
+    d->obst_min_s = p->crash_min_s - p->min_allowed;
+    d->max_pred_decel = p->max_pred_decel; d->follow_gap = p->follow_gap; d->react_thr = p->react_thr;
+    d->crash_thr = p->crash_thr; d->crash_dist_thr = p->comb_min_dist - p->car_length;
+    d->H = H;
+    d->dlen = (int)(p->car_length / p->ds);      // st.py:37
+    for (int t = 0; t < H; ++t) {
+        d->unc[t] = p->start_unc + p->unc_per_s * tv[t];   // st.py:40
+        d->dunc[t] = (int)(d->unc[t] / p->ds);             // st.py:41
+    }
+    return STMPC_OK;
+}
+
+template <int KMAX>
+void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
+                    CarTab tab, unsigned *counters, hipStream_t st) {
+    int blocks = (N + 63) / 64;
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters);
+}
+
+}  // namespace
+
+extern "C" {
+
+int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego,
+                             const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
+                             int32_t *d_bt, double *d_cost, double *d_pd, int32_t *d_crash, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N or Kmax out of range");
+    if (N == 0) return STMPC_OK;
+    if (!d_ego || !d_k || !d_path || !d_bt || !d_cost) return fail(STMPC_EINVAL, "NULL device pointer");
+    if (Kmax > 0 && (!d_ox || !d_ov)) return fail(STMPC_EINVAL, "NULL device pointer (other_x/other_v)");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    DevP dp;
+    int rc = make_devp(p, &dp);
+    if (rc) return rc;
+    const int H = dp.H;
+    const int S_nom = stmpc_num_s(p, 0.0);
+    if (S_nom < 2 || S_nom + 2 > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "number of position cells out of range");
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+
+    // scratch
+    if ((rc = c->tab_edge.ensure((size_t)N * H * Kalloc * 2 * sizeof(double)))) return rc;
+    if ((rc = c->tab_win.ensure((size_t)N * H * Kalloc * 2 * sizeof(int)))) return rc;
+    if ((rc = c->tab_nact.ensure((size_t)N * H * sizeof(int)))) return rc;
+    if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
+    if ((rc = c->counters.ensure(64))) return rc;
+    if ((rc = c->overflow.ensure((size_t)N * sizeof(int)))) return rc;
+
+    const int W = c->fast_W;
+    const size_t lds_bytes = (size_t)W * 30;
+    int per_cu = (int)((size_t)(160 * 1024) / (lds_bytes + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 16) per_cu = 16;
+    int grid_fast = c->num_cu * per_cu;
+    if (grid_fast > N) grid_fast = N;
+    if ((rc = c->bp.ensure((size_t)grid_fast * H * W * sizeof(u16)))) return rc;
+
+    const int Wg = next_pow2(S_nom + 2);
+    int grid_fb = c->num_cu * 4;
+    if (grid_fb > N) grid_fb = N;
+    if ((rc = c->gscratch.ensure((size_t)grid_fb * Wg * 30))) return rc;
+    if ((rc = c->bp_fb.ensure((size_t)grid_fb * H * Wg * sizeof(u16)))) return rc;
+
+    CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
+    unsigned *counters = c->counters.as<unsigned>();
+
+    HIPCHK(hipEventRecord(c->ev0, st));
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
+
+    SolveArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = dp; a.N = N; a.Kmax = Kalloc; a.W = W; a.only_flagged = 0;
+    a.ego = d_ego; a.tab = tab;
+    a.bp = c->bp.as<u16>(); a.gscratch = nullptr; a.counters = counters; a.overflow_list = c->overflow.as<int>();
+    a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
+
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipEventRecord(c->ev1, st));
+    hipLaunchKernelGGL((k_solve<true, false>), dim3(grid_fast), dim3(64), lds_bytes, st, a);
+    HIPCHK(hipEventRecord(c->ev2, st));
+
+    // second tier: episodes whose reachable span overflowed the LDS window (list built on device)
+    SolveArgs b = a;
+    b.W = Wg; b.only_flagged = 1; b.bp = c->bp_fb.as<u16>(); b.gscratch = c->gscratch.as<unsigned char>();
+    hipLaunchKernelGGL((k_solve<false, false>), dim3(grid_fb), dim3(64), 0, st, b);
+    HIPCHK(hipEventRecord(c->ev3, st));
+    HIPCHK(hipGetLastError());
+    c->stats.episodes = N;
+    c->stats_pending = true;
+    return STMPC_OK;
+}
+
+int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
+    if (!c || !out) return fail(STMPC_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->stats_pending) {
+        HIPCHK(hipEventSynchronize(c->ev3));
+        unsigned cnt[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+        float ms_all = 0.f, ms_dp = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms_all, c->ev0, c->ev3));
+        HIPCHK(hipEventElapsedTime(&ms_dp, c->ev1, c->ev2));
+        c->stats.fallback = cnt[1];
+        c->stats.fast_path = c->stats.episodes - cnt[1];
+        c->stats.retries = 0;
+        c->stats.solve_ms = ms_all;
+        c->stats.dp_kernel_ms = ms_dp;
+        c->stats_pending = false;
+        if (cnt[3]) { *out = c->stats; return fail(STMPC_EINTERNAL, "solver error flag set on device"); }
+    }
+    *out = c->stats;
+    return STMPC_OK;
+}
+
+int stmpc_solve_batch(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *ego, const int32_t *k,
+                      const double *ox, const double *ov, int32_t *path, int32_t *bt, double *cost, double *pd,
+                      int32_t *crash) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N or Kmax out of range");
+    if (N == 0) return STMPC_OK;
+    if (!ego || !k || !path || !bt || !cost) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (Kmax > 0 && (!ox || !ov)) return fail(STMPC_EINVAL, "NULL host pointer (other_x/other_v)");
+    for (int i = 0; i < N; ++i) if (k[i] < 0 || k[i] > Kmax) return fail(STMPC_EINVAL, "k_count[i] outside [0, Kmax]");
+    HIPCHK(hipSetDevice(c->device));
+    int H = stmpc_num_t(p);
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "number of time layers must be in [2, 64]");
+    int rc;
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+    if ((rc = c->s_ego.ensure((size_t)N * 5 * 8))) return rc;
+    if ((rc = c->s_k.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->s_ox.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_ov.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_path.ensure((size_t)N * H * 4))) return rc;
+    if ((rc = c->s_bt.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->s_cost.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->s_pd.ensure((size_t)N * H * 8))) return rc;
+    if ((rc = c->s_crash.ensure((size_t)N * 4))) return rc;
+    HIPCHK(hipMemcpy(c->s_ego.p, ego, (size_t)N * 5 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_k.p, k, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (Kmax > 0) {
+        HIPCHK(hipMemcpy(c->s_ox.p, ox, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->s_ov.p, ov, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+    }
+    rc = stmpc_solve_batch_device(c, p, N, Kmax, c->s_ego.as<double>(), c->s_k.as<int32_t>(), c->s_ox.as<double>(),
+                                  c->s_ov.as<double>(), c->s_path.as<int32_t>(), c->s_bt.as<int32_t>(),
+                                  c->s_cost.as<double>(), c->s_pd.as<double>(), c->s_crash.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(path, c->s_path.p, (size_t)N * H * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bt, c->s_bt.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cost, c->s_cost.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (pd) HIPCHK(hipMemcpy(pd, c->s_pd.p, (size_t)N * H * 8, hipMemcpyDeviceToHost));
+    if (crash) HIPCHK(hipMemcpy(crash, c->s_crash.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    stmpc_stats s;
+    return stmpc_get_stats(c, &s);
+}
+
+int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_values, int S, const double *t_values,
+                     int H, double v0, double a0, const double *distances, double d_w, double v_w, double a_w,
+                     double j_w, double v_des, double v_max, double a_min, double a_max, double j_min, double j_max,
+                     double min_allowed, double *s_sequence_out) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (!obstacles || !s_values || !t_values || !distances || !s_sequence_out) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "num_t must be in [2, 64]");
+    if (S < 2 || S > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "num_s must be in [2, 65000]");
+    HIPCHK(hipSetDevice(c->device));
+    DevP dp;
+    memset(&dp, 0, sizeof dp);
+    dp.dt = t_values[1] - t_values[0];           // st_cy.pyx:319
+    if (dp.dt == 0.0) return fail(STMPC_EINVAL, "float division by zero (delta_t == 0)");   // ZeroDivisionError in the reference
+    if (s_values[1] - s_values[0] == 0.0) return fail(STMPC_EINVAL, "float division by zero (delta_s == 0)");
+    dp.dt2 = dp.dt * dp.dt; dp.dt3 = host_pow(dp.dt, 3.0);
+    dp.d_w = d_w; dp.v_w = v_w; dp.a_w = a_w; dp.j_w = j_w; dp.v_des = v_des; dp.v_max = v_max; dp.a_min = a_min;
+    dp.a_max = a_max; dp.j_min = j_min; dp.j_max = j_max; dp.min_allowed = min_allowed;
+    dp.crash_dist_thr = -1.0; dp.H = H;
+    int rc;
+    const size_t cells = (size_t)H * S;
+    if ((rc = c->s_misc0.ensure(cells))) return rc;
+    if ((rc = c->s_misc1.ensure(cells * 8))) return rc;
+    if ((rc = c->s_misc2.ensure((size_t)S * 8))) return rc;
+    if ((rc = c->s_misc3.ensure((size_t)H * 8))) return rc;
+    if ((rc = c->counters.ensure(64))) return rc;
+    const int Wg = next_pow2(S + 2);
+    if ((rc = c->gscratch.ensure((size_t)Wg * 30))) return rc;
+    if ((rc = c->bp_fb.ensure((size_t)H * Wg * sizeof(u16)))) return rc;
+    HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_misc2.p, s_values, (size_t)S * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->counters.p, 0, 64));
+    SolveArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg;
+    a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
+    a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
+    a.bp = c->bp_fb.as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
+    a.s_sequence = c->s_misc3.as<double>();
+    hipLaunchKernelGGL((k_solve<false, true>), dim3(1), dim3(64), 0, nullptr, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));
+    unsigned cnt[4];
+    HIPCHK(hipMemcpy(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+    if (cnt[3]) return fail(STMPC_EINTERNAL, "grid solver reported a window overflow");
+    return STMPC_OK;
+}
+
+int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, int k, const double *ox,
+                     const double *ov, uint8_t *obstacles, double *distances, double *s_values, double *t_values) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (!state5 || !obstacles || !distances || !s_values || !t_values) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (k < 0 || k > STMPC_KMAX_LIMIT || (k > 0 && (!ox || !ov))) return fail(STMPC_EINVAL, "bad vehicle count / arrays");
+    HIPCHK(hipSetDevice(c->device));
+    DevP dp;
+    int rc = make_devp(p, &dp);
+    if (rc) return rc;
+    const int H = dp.H;
+    const double start_s = state5[4];
+    const int S = stmpc_num_s(p, start_s);
+    if (S < 2 || S > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "number of position cells out of range");
+    const int Kalloc = k > 0 ? k : 1;
+    if ((rc = c->tab_edge.ensure((size_t)H * Kalloc * 2 * 8))) return rc;
+    if ((rc = c->tab_win.ensure((size_t)H * Kalloc * 2 * 4))) return rc;
+    if ((rc = c->tab_nact.ensure((size_t)H * 4))) return rc;
+    if ((rc = c->tab_nums.ensure(4))) return rc;
+    if ((rc = c->counters.ensure(64))) return rc;
+    if ((rc = c->s_ego.ensure(5 * 8))) return rc;
+    if ((rc = c->s_k.ensure(4))) return rc;
+    if ((rc = c->s_ox.ensure((size_t)Kalloc * 8))) return rc;
+    if ((rc = c->s_ov.ensure((size_t)Kalloc * 8))) return rc;
+    const size_t cells = (size_t)H * S;
+    if ((rc = c->s_misc0.ensure(cells))) return rc;
+    if ((rc = c->s_misc1.ensure(cells * 8))) return rc;
+    if ((rc = c->s_misc2.ensure((size_t)S * 8))) return rc;
+    HIPCHK(hipMemcpy(c->s_ego.p, state5, 5 * 8, hipMemcpyHostToDevice));
+    int32_t kk = k;
+    HIPCHK(hipMemcpy(c->s_k.p, &kk, 4, hipMemcpyHostToDevice));
+    if (k > 0) {
+        HIPCHK(hipMemcpy(c->s_ox.p, ox, (size_t)k * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->s_ov.p, ov, (size_t)k * 8, hipMemcpyHostToDevice));
+    }
+    CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
+    unsigned *counters = c->counters.as<unsigned>();
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
+    dim3 grid((S + 255) / 256, H);
+    hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
+                       c->s_misc1.as<double>(), c->s_misc2.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(obstacles, c->s_misc0.p, cells, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(distances, c->s_misc1.p, cells * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s_values, c->s_misc2.p, (size_t)S * 8, hipMemcpyDeviceToHost));
+    host_t_values(p, H, t_values);
+    return STMPC_OK;
+}
+
+int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, int Kmax, const double *ego4,
+                        const int32_t *k, const double *ox, const double *ov, const double *sel, double dt,
+                        double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || (mode != 0 && mode != 1)) return fail(STMPC_EINVAL, "bad N/Kmax/mode");
+    if (N == 0) return STMPC_OK;
+    if (!ego4 || !k || !ego4_out || !crashed || (mode == 0 && !sel)) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (Kmax > 0 && (!ox || !ov || !ox_out || !ov_out)) return fail(STMPC_EINVAL, "NULL host pointer (vehicles)");
+    for (int i = 0; i < N; ++i) if (k[i] < 0 || k[i] > Kmax) return fail(STMPC_EINVAL, "k_count[i] outside [0, Kmax]");
+    HIPCHK(hipSetDevice(c->device));
+    DevP dp;
+    int rc = make_devp(p, &dp);
+    if (rc) return rc;
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+    if ((rc = c->s_ego.ensure((size_t)N * 5 * 8))) return rc;
+    if ((rc = c->s_k.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->s_ox.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_ov.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_misc0.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->s_misc1.ensure((size_t)N * 4 * 8))) return rc;
+    if ((rc = c->s_misc2.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_misc3.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_crash.ensure((size_t)N * 4))) return rc;
+    HIPCHK(hipMemcpy(c->s_ego.p, ego4, (size_t)N * 4 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_k.p, k, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (Kmax > 0) {
+        HIPCHK(hipMemcpy(c->s_ox.p, ox, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->s_ov.p, ov, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+    }
+    if (mode == 0) HIPCHK(hipMemcpy(c->s_misc0.p, sel, (size_t)N * 8, hipMemcpyHostToDevice));
+    int blocks = (N + 63) / 64;
+#define STMPC_LAUNCH_STEP(KM)                                                                                         \
+    hipLaunchKernelGGL(k_predict_step<KM>, dim3(blocks), dim3(64), 0, nullptr, dp, mode, N, Kalloc, c->s_ego.as<double>(), \
+                       c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), c->s_misc0.as<double>(), dt, mcd,   \
+                       c->s_misc1.as<double>(), c->s_misc2.as<double>(), c->s_misc3.as<double>(), c->s_crash.as<int>())
+    if (Kalloc <= 8) STMPC_LAUNCH_STEP(8);
+    else if (Kalloc <= 16) STMPC_LAUNCH_STEP(16);
+    else STMPC_LAUNCH_STEP(32);
+#undef STMPC_LAUNCH_STEP
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(ego4_out, c->s_misc1.p, (size_t)N * 4 * 8, hipMemcpyDeviceToHost));
+    if (Kmax > 0) {
+        HIPCHK(hipMemcpy(ox_out, c->s_misc2.p, (size_t)N * Kmax * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ov_out, c->s_misc3.p, (size_t)N * Kmax * 8, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(crashed, c->s_crash.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    return STMPC_OK;
+}
+
+int stmpc_probe_arith(stmpc_ctx *c, int op, const double *a, const double *b, double *out, int n) {
+    if (!c || !a || !out || n < 0) return fail(STMPC_EINVAL, "bad argument");
+    if (n == 0) return STMPC_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->s_misc0.ensure((size_t)n * 8))) return rc;
+    if ((rc = c->s_misc1.ensure((size_t)n * 8))) return rc;
+    if ((rc = c->s_misc2.ensure((size_t)n * 8))) return rc;
+    HIPCHK(hipMemcpy(c->s_misc0.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (b) HIPCHK(hipMemcpy(c->s_misc1.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_probe, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, c->s_misc0.as<double>(),
+                       b ? c->s_misc1.as<double>() : nullptr, c->s_misc2.as<double>(), n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->s_misc2.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return STMPC_OK;
+}
+
+}  // extern "C"

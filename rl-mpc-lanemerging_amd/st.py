@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's ST ("MPC") interface, backed by the HIP solver.
+
+Same names, argument meaning and failure conventions as the reference's ``st.py`` /
+``st_cy.pyx`` for the hot path, so a caller written against the reference
+(``control.run_episode``'s ``control_function(state)`` protocol at control.py:310, or
+``dqn.RLAgent.do_combined_control`` at dqn.py:117-200) can switch modules:
+
+    solve_s_t_path_fast(...)                      <- st_cy.solve_s_t_path_fast          st_cy.pyx:315
+    find_s_t_obstacles_from_state(...)            <- st.find_s_t_obstacles_from_state   st.py:25
+    get_appropriate_base_st_path_and_obstacles(s) <- same name                          st.py:726
+    do_st_control(state)                          <- same name                          st.py:757
+    test_guaranteed_crash_from_state(state)       <- same name                          st.py:790
+    get_path_mean_abs_jerk(...)                   <- same name                          st.py:274
+    get_range_index(...)                          <- same name                          st.py:20
+
+plus the batched entry the reference does not have: ``solve_states`` / ``solve_arrays``.
+All lattice work runs on the GPU through ``libstmpc.so``; nothing here falls back to a
+CPU implementation.
+"""
+import numpy as np
+
+from . import _capi
+from . import control
+from .config import Settings
+from .prediction import HighwayState, pack_states  # noqa: F401  (re-export)
+
+
+def get_range_index(min_s, delta_s, s):
+    # st.py:20-22
+    return int((s - min_s) / delta_s)
+
+
+def _params_from_settings():
+    return _capi.Params.from_settings(Settings)
+
+
+def s_values_for(start_s, params, num_s=None):
+    """The solver's s lookup table, ``np.arange(start_s, start_s + future_s + ds, ds)`` (st.py:31)."""
+    if num_s is None:
+        num_s = _capi.num_s(params, start_s)
+    return np.arange(start_s, start_s + params.future_s + params.ds, params.ds)[:num_s]
+
+
+def solve_s_t_path_fast(obstacles_bool, s_values, t_indices, ego_start_speed, ego_start_acceleration, distances,
+                        d_weight, v_weight, a_weight, j_weight, desired_speed, max_speed,
+                        negative_acceleration_limit, positive_acceleration_limit, negative_jerk_limit,
+                        positive_jerk_limit, min_allowed_distance):
+    """Drop-in for ``st_cy.solve_s_t_path_fast`` (st_cy.pyx:315-399): 17 positional arguments,
+    returns a fresh ``ndarray[num_t]`` of s along the path with 0.0 past the deepest layer reached."""
+    s_values = np.asarray(s_values, dtype=np.float64)
+    t_indices = np.asarray(t_indices, dtype=np.float64)
+    if s_values.shape[0] < 2 or t_indices.shape[0] < 2:
+        raise IndexError("s_values and t_indices need at least two entries")   # st_cy.pyx:318-319
+    if t_indices[1] - t_indices[0] == 0:
+        raise ZeroDivisionError("float division")                             # cdivision off in the reference
+    return _capi.default_context().solve_grid(
+        np.asarray(obstacles_bool), s_values, t_indices, ego_start_speed, ego_start_acceleration,
+        np.asarray(distances, dtype=np.float64),
+        (d_weight, v_weight, a_weight, j_weight, desired_speed, max_speed, negative_acceleration_limit,
+         positive_acceleration_limit, negative_jerk_limit, positive_jerk_limit, min_allowed_distance))
+
+
+def find_s_t_obstacles_from_state(current_state, future_s=150, delta_s=0.5, delta_t=0.2, time_limit=5,
+                                  start_uncertainty=0.0, uncertainty_per_second=0.1):
+    """st.py:25-70 on the GPU: returns ``(obstacles, s_values, t_values, ego_speed, distances)``."""
+    params = _params_from_settings()
+    params.future_s, params.ds, params.dt, params.future_t = future_s, delta_s, delta_t, time_limit
+    params.start_unc, params.unc_per_s = start_uncertainty, uncertainty_per_second
+    start_s = control.get_ego_s(current_state.ego_position)
+    state5 = np.array([current_state.ego_position[0], current_state.ego_position[1], current_state.ego_speed,
+                       current_state.ego_acceleration, start_s], dtype=np.float64)
+    obstacles, s_values, t_values, distances = _capi.default_context().build_grid(
+        params, state5, np.asarray(current_state.other_xs, dtype=np.float64),
+        np.asarray(current_state.other_speeds, dtype=np.float64))
+    return obstacles, s_values, t_values, current_state.ego_speed, distances
+
+
+def solve_arrays(ego, k_count, other_x, other_v, params=None, ctx=None, want_dist=True):
+    """Batched solve on SoA arrays (see ``pack_states``).  Returns a dict with ``path_idx[N,H]``,
+    ``best_t[N]``, ``cost[N]``, ``path_dist[N,H]``, ``crash[N]``."""
+    params = params or _params_from_settings()
+    ctx = ctx or _capi.default_context()
+    path, best_t, cost, pdist, crash = ctx.solve_batch(params, ego, k_count, other_x, other_v, want_dist)
+    return {"path_idx": path, "best_t": best_t, "cost": cost, "path_dist": pdist, "crash": crash}
+
+
+def s_sequence_from_path(path_idx_row, start_s, params):
+    """Rebuild the reference's return value: s along the path, 0.0 past ``best_t`` (st_cy.pyx:393-398)."""
+    sv = s_values_for(start_s, params)
+    out = np.zeros(path_idx_row.shape[0], dtype=np.float64)
+    ok = path_idx_row >= 0
+    out[ok] = sv[path_idx_row[ok]]
+    return out
+
+
+def solve_states(states, params=None, ctx=None):
+    """Batched ``get_appropriate_base_st_path_and_obstacles`` without the grids:
+    returns ``(s_sequences[N,H], result_dict)``."""
+    params = params or _params_from_settings()
+    ego, k_count, ox, ov = pack_states(states)
+    res = solve_arrays(ego, k_count, ox, ov, params, ctx)
+    seqs = np.stack([s_sequence_from_path(res["path_idx"][i], ego[i, 4], params) for i in range(len(states))]) \
+        if len(states) else np.zeros((0, _capi.num_t(params)))
+    return seqs, res
+
+
+def get_appropriate_base_st_path_and_obstacles(state):
+    """st.py:726-754: ``(s_sequence, obstacles, s_values, t_values, distances)`` for one state."""
+    obstacles, s_values, t_values, ego_speed, distances = find_s_t_obstacles_from_state(
+        state, Settings.FUTURE_S, Settings.S_DISCRETIZATION, Settings.T_DISCRETIZATION, Settings.FUTURE_T,
+        Settings.START_UNCERTAINTY, Settings.UNCERTAINTY_PER_SECOND)
+    if not Settings.USE_FAST_ST_SOLVER:
+        raise NotImplementedError("only the production solver (USE_FAST_ST_SOLVER=True, st.py:738-746) is built; "
+                                  "the no-jerk variants (st_cy.pyx:96,209) are SURVEY row f4")
+    seqs, _ = solve_states([state])
+    return seqs[0], obstacles, s_values, t_values, distances
+
+
+#: Optional QP smoother with the signature of the reference's ``st.finer_fit`` (st.py:584).  The
+#: reference applies it whenever TICK_LENGTH < T_DISCRETIZATION (st.py:770-772); it needs cvxopt and
+#: is SURVEY row f1 ("next").  While it is None, ``do_st_control`` commands the lattice's own
+#: first-step speed (s[1]-s[0]) / T_DISCRETIZATION instead of the QP-resampled one.
+finer_fit = None
+
+
+def do_st_control(state):
+    """st.py:757-783.  Returns the commanded speed and forwards it to ``control.set_ego_speed``."""
+    ego_acceleration = state.ego_acceleration
+    ego_speed = state.ego_speed
+    seqs, _ = solve_states([state])
+    s_sequence = seqs[0]
+
+    end_point = len(s_sequence)
+    while s_sequence[end_point - 1] == 0:
+        end_point -= 1
+    if end_point != len(s_sequence):
+        print("ST Solver finds crash inevitable")
+    s_sequence = s_sequence[:end_point]
+
+    step_time = Settings.TICK_LENGTH
+    if Settings.TICK_LENGTH < Settings.T_DISCRETIZATION:
+        if finer_fit is not None:
+            s_sequence = finer_fit(s_sequence, Settings.TICK_LENGTH, Settings.T_DISCRETIZATION, ego_speed,
+                                   ego_acceleration)
+        else:
+            step_time = Settings.T_DISCRETIZATION
+
+    if len(s_sequence) <= 1:
+        control.set_ego_speed(ego_speed)
+        return ego_speed
+
+    planned_distance_first_step = s_sequence[1] - s_sequence[0]
+    end_speed_first_step = planned_distance_first_step / step_time
+    control.set_ego_speed(end_speed_first_step)
+    return end_speed_first_step
+
+
+def test_guaranteed_crash_from_state(state):
+    """st.py:790-802."""
+    _, res = solve_states([state])
+    return bool(res["crash"][0])
+
+
+test_guaranteed_crash_from_state.__test__ = False   # not a pytest test
+
+
+def get_path_mean_abs_jerk(s_sequence, ego_start_speed, ego_start_acceleration, delta_t):
+    # st.py:274-288
+    prev_a = ego_start_acceleration
+    prev_v = ego_start_speed
+    path_cost = 0
+    for i, s in enumerate(s_sequence):
+        if i == 0:
+            continue
+        s_1 = s_sequence[i - 1]
+        v = (s - s_1) / delta_t
+        a = (v - prev_v) / delta_t
+        j = (a - prev_a) / delta_t
+        prev_v = v
+        prev_a = a
+        path_cost += abs(j)
+    return path_cost / (len(s_sequence) - 1)
