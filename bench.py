@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC (ST lattice) solves/s on MI355X.
+
+Workload (BASELINE.json configs[1]): batched synthetic merge states, 4096 episodes per GPU,
+H = 40 time layers, fan-out A = 20-21 (SURVEY 8d mapping: S = 7201 cells), K = 6 neighbours, fp64.
+One "step" = one pass of the hot path (traffic prediction -> lattice DP -> path/cost/crash
+outputs) over the batch, inputs already resident in HBM; with --gpus N each rank solves its own
+4096 episodes (weak scaling) and the ranks all-gather the chosen (action, cost) over RCCL.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--episodes", type=int, default=4096, help="episodes per GPU")
+    ap.add_argument("--workload", choices=["h40a21", "default"], default="h40a21")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, sharding, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    if args.workload == "h40a21":
+        pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    params = _capi.Params.from_settings(pkg.Settings)
+    H, S_nom = _capi.num_t(params), _capi.num_s(params, 0.0)
+    n, K, Kmax = args.episodes, 6, 8
+    ego, kc, ox, ov = synth.generate_states(n, k=K, kmax=Kmax, seed=1000 + rank)
+
+    ctx = _capi.Context(local_rank)
+    d_ego = torch.as_tensor(ego, device=dev)
+    d_k = torch.as_tensor(kc, device=dev)
+    d_ox = torch.as_tensor(ox, device=dev)
+    d_ov = torch.as_tensor(ov, device=dev)
+    d_path = torch.empty((n, H), dtype=torch.int32, device=dev)
+    d_bt = torch.empty(n, dtype=torch.int32, device=dev)
+    d_cost = torch.empty(n, dtype=torch.float64, device=dev)
+    d_pd = torch.empty((n, H), dtype=torch.float64, device=dev)
+    d_crash = torch.empty(n, dtype=torch.int32, device=dev)
+    gathered = torch.empty((n * world, 2), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.solve_batch_device(params, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
+                               d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_pd.data_ptr(),
+                               d_crash.data_ptr(), stream)
+        if world > 1:
+            sharding.gather_actions(sharding.pack_actions(d_path, d_cost), world, gathered)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = ctx.stats() if False else None
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (the LDS lattice-DP kernel), from HIP events on the launch stream
+    bytes_per_solve = 140 + 16 + 4 * H        # state in (K=6) + action/cost/best_t + path_idx[H]
+    dp_ms = prof["dp_kernel_ms"] / max(prof["launches"], 1)
+    achieved_gbs = bytes_per_solve * n / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "stmpc::k_solve<true,false>", "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve,
+                "note": "algorithmic HBM bytes are ~316 B/solve: the path is fp64-VALU/LDS bound, see fp64_valu"}
+
+    out = {"metric": "MPC solves/sec (H=40,A=21,K=6)" if args.workload == "h40a21" else "MPC solves/sec (reference default H=18,S=3001,K=6)",
+           "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "batched synthetic merge states N=%d/GPU, H=%d, S=%d, fan-out<=21, K=%d, fp64"
+                                  % (n, H, S_nom, K) if args.workload == "h40a21" else
+                                  "batched synthetic merge states N=%d/GPU, reference default lattice H=%d, S=%d, K=%d, fp64" % (n, H, S_nom, K),
+                      "episodes_per_gpu": n, "H": H, "S": S_nom, "K": K,
+                      "collective": "all_gather(action,cost) 16 B/episode" if world > 1 else "none"},
+           "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import st_oracle as orc
+        op = orc.OrcParams.from_dict(params.as_dict())
+        cores = os.cpu_count() or 1
+        # calibrate on a few episodes, then size the sample for ~cpu-seconds of wall time
+        c0 = time.perf_counter()
+        orc.solve_batch(op, ego[:cores], kc[:cores], ox[:cores], ov[:cores], solver="layered", nthreads=cores)
+        per_round = max(time.perf_counter() - c0, 1e-4)
+        m = int(min(n, max(cores, cores * args.cpu_seconds / per_round)))
+        c0 = time.perf_counter()
+        ref = orc.solve_batch(op, ego[:m], kc[:m], ox[:m], ov[:m], solver="layered", nthreads=cores)
+        cpu_s = time.perf_counter() - c0
+        flops = 27 * ref["edges"] + 26 * ref["nodes"] + 6 * K * ref["cells"] + 40 * K * H * m
+        got = {"path_idx": d_path[:m].cpu().numpy(), "best_t": d_bt[:m].cpu().numpy(), "cost": d_cost[:m].cpu().numpy(),
+               "crash": d_crash[:m].cpu().numpy()}
+        parity = {k: bool(np.array_equal(got[k], ref[k])) for k in got}
+        out["cpu_baseline"] = {"value": m / cpu_s, "unit": "solves/s", "cores": cores, "kind": "port",
+                               "sample": "first %d episodes of the same batch, oracle layered DP (oracle/st_oracle.c), %d threads, %.1f s"
+                                         % (m, cores, cpu_s)}
+        out["parity_vs_oracle"] = {"episodes": m, **parity}
+        flops_per_solve = flops / m
+        out["fp64_valu"] = {"algorithmic_flops_per_solve": flops_per_solve,
+                            "achieved_tflops": flops_per_solve * n / (dp_ms * 1e-3) / 1e12 if dp_ms > 0 else 0.0,
+                            "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                            "frac": (flops_per_solve * n / (dp_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if dp_ms > 0 else 0.0,
+                            "edges_per_solve": ref["edges"] / m, "nodes_per_solve": ref["nodes"] / m}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

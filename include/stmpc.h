@@ -75,6 +75,14 @@ typedef struct stmpc_stats {
     double  dp_kernel_ms;    /* device time of the lattice DP kernel alone */
 } stmpc_stats;
 
+/* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */
+typedef struct stmpc_profile_totals {
+    int64_t launches;        /* stmpc_solve_batch_device calls */
+    int64_t episodes;        /* sum of N */
+    double  solve_ms;        /* sum of device time, predictor + DP + second tier (HIP events on the launch stream) */
+    double  dp_kernel_ms;    /* sum of device time of the LDS lattice-DP kernel */
+} stmpc_profile_totals;
+
 typedef struct stmpc_ctx stmpc_ctx;
 
 /* Library / device identification, e.g. "stmpc 0.1 hip gfx950 AMD Instinct MI355X cu=256". */
@@ -119,6 +127,11 @@ int stmpc_solve_batch(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
                       double *path_dist, int32_t *crash);
 
 int stmpc_get_stats(stmpc_ctx *ctx, stmpc_stats *out);
+
+/* enable != 0: start timing every subsequent stmpc_solve_batch_device launch with its own HIP events (no host
+ * synchronisation is added to the launches).  enable == 0: wait for those launches, sum their device times into
+ * *out (may be NULL) and stop.  While profiling, stmpc_get_stats reports nothing new. */
+int stmpc_profile(stmpc_ctx *ctx, int enable, stmpc_profile_totals *out);
 
 /*
  * Single-episode entry with materialised grids: st_cy.solve_s_t_path_fast's exact

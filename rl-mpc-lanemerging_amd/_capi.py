@@ -50,12 +50,16 @@ class Stats(C.Structure):
                 ("retries", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
 
 
+class ProfileTotals(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("episodes", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
+
+
 _lib = None
 
 EXPORTS = (
     "stmpc_backend_info", "stmpc_last_error", "stmpc_create", "stmpc_destroy", "stmpc_ego_s", "stmpc_num_s",
     "stmpc_num_t", "stmpc_path_mean_abs_jerk", "stmpc_solve_batch_device", "stmpc_solve_batch", "stmpc_get_stats",
-    "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith",
+    "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
 )
 
 
@@ -94,6 +98,7 @@ def load():
     lib.stmpc_predict_batch.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
                                         dp, dp, dp, ip]
     lib.stmpc_probe_arith.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    lib.stmpc_profile.argtypes = [vp, C.c_int, C.POINTER(ProfileTotals)]
     _lib = lib
     return lib
 
@@ -180,6 +185,14 @@ class Context:
         self._chk(self._lib.stmpc_solve_batch_device(self._h, C.byref(params), int(N), int(Kmax), d_ego, d_k, d_ox,
                                                      d_ov, d_path, d_bt, d_cost, d_pd or None, d_crash or None,
                                                      stream or None))
+
+    def profile_begin(self):
+        self._chk(self._lib.stmpc_profile(self._h, 1, None))
+
+    def profile_end(self):
+        t = ProfileTotals()
+        self._chk(self._lib.stmpc_profile(self._h, 0, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in ProfileTotals._fields_}
 
     def stats(self):
         s = Stats()

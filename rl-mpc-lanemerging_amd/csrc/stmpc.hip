@@ -65,6 +65,12 @@ struct stmpc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
     bool stats_pending = false;
+    // profiling pool: one (begin, dp-begin, dp-end, end) event quad per launch while enabled
+    bool profiling = false;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;          // events used (multiple of 4)
+    double acc_solve_ms = 0, acc_dp_ms = 0;
+    int64_t acc_launches = 0, acc_fallback = 0, acc_episodes = 0;
     int fast_W = 1024;          // LDS window (cells) of the fast tier
     int fast_blocks_per_cu = 5;
 };
@@ -128,6 +134,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
     if (c->ev3) (void)hipEventDestroy(c->ev3);
+    for (hipEvent_t ev : c->pool) (void)hipEventDestroy(ev);
     delete c;
 }
 
@@ -259,7 +266,15 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
 
-    HIPCHK(hipEventRecord(c->ev0, st));
+    hipEvent_t e0 = c->ev0, e1 = c->ev1, e2 = c->ev2, e3 = c->ev3;
+    if (c->profiling) {
+        if (c->pool_used + 4 > c->pool.size()) {
+            for (int i = 0; i < 4; ++i) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); c->pool.push_back(ev); }
+        }
+        e0 = c->pool[c->pool_used]; e1 = c->pool[c->pool_used + 1]; e2 = c->pool[c->pool_used + 2]; e3 = c->pool[c->pool_used + 3];
+        c->pool_used += 4;
+    }
+    HIPCHK(hipEventRecord(e0, st));
     if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
     else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
     else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
@@ -272,18 +287,19 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
     HIPCHK(hipFuncSetAttribute((const void *)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipEventRecord(c->ev1, st));
+    HIPCHK(hipEventRecord(e1, st));
     hipLaunchKernelGGL((k_solve<true, false>), dim3(grid_fast), dim3(64), lds_bytes, st, a);
-    HIPCHK(hipEventRecord(c->ev2, st));
+    HIPCHK(hipEventRecord(e2, st));
 
     // second tier: episodes whose reachable span overflowed the LDS window (list built on device)
     SolveArgs b = a;
     b.W = Wg; b.only_flagged = 1; b.bp = c->bp_fb.as<u16>(); b.gscratch = c->gscratch.as<unsigned char>();
     hipLaunchKernelGGL((k_solve<false, false>), dim3(grid_fb), dim3(64), 0, st, b);
-    HIPCHK(hipEventRecord(c->ev3, st));
+    HIPCHK(hipEventRecord(e3, st));
     HIPCHK(hipGetLastError());
     c->stats.episodes = N;
-    c->stats_pending = true;
+    c->stats_pending = !c->profiling;
+    if (c->profiling) { c->acc_launches += 1; c->acc_episodes += N; }
     return STMPC_OK;
 }
 
@@ -306,6 +322,31 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         if (cnt[3]) { *out = c->stats; return fail(STMPC_EINTERNAL, "solver error flag set on device"); }
     }
     *out = c->stats;
+    return STMPC_OK;
+}
+
+int stmpc_profile(stmpc_ctx *c, int enable, stmpc_profile_totals *out) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (enable) {
+        c->profiling = true; c->pool_used = 0;
+        c->acc_solve_ms = c->acc_dp_ms = 0; c->acc_launches = c->acc_fallback = c->acc_episodes = 0;
+        return STMPC_OK;
+    }
+    // disable: drain the pool
+    for (size_t i = 0; i + 3 < c->pool_used; i += 4) {
+        HIPCHK(hipEventSynchronize(c->pool[i + 3]));
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, c->pool[i], c->pool[i + 3]));
+        HIPCHK(hipEventElapsedTime(&b, c->pool[i + 1], c->pool[i + 2]));
+        c->acc_solve_ms += a; c->acc_dp_ms += b;
+    }
+    c->pool_used = 0;
+    c->profiling = false;
+    if (out) {
+        out->launches = c->acc_launches; out->episodes = c->acc_episodes;
+        out->solve_ms = c->acc_solve_ms; out->dp_kernel_ms = c->acc_dp_ms;
+    }
     return STMPC_OK;
 }
 

@@ -1,0 +1,138 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host helpers are exact,
+the host-side mirror behaves like the reference's interface, and the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+
+def _lib():
+    import rl_mpc_lanemerging_amd as pkg
+    if pkg.build.needs_build():
+        pkg.build.build()
+    from rl_mpc_lanemerging_amd import _capi
+    return _capi
+
+
+def test_library_exports_every_declared_symbol():
+    capi = _lib()
+    lib = capi.load()
+    header = open(os.path.join(REPO, "include", "stmpc.h")).read()
+    declared = set(re.findall(r"\b(stmpc_[a-z_0-9]+)\s*\(", header))
+    declared -= {"stmpc_params", "stmpc_stats", "stmpc_ctx"}
+    assert declared == set(capi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_params_struct_layout_matches_header():
+    capi = _lib()
+    header = open(os.path.join(REPO, "include", "stmpc.h")).read()
+    body = header[header.index("typedef struct stmpc_params {"):header.index("} stmpc_params;")]
+    names = []
+    for line in body.splitlines():
+        line = line.split("/*")[0].strip()
+        if line.startswith("double"):
+            names += [n.strip() for n in line[len("double"):].rstrip(";").split(",")]
+    assert names == [n for n, _ in capi.Params._fields_]
+    assert ctypes.sizeof(capi.Params) == 8 * len(names)
+
+
+def test_host_helpers_match_reference_golden():
+    capi = _lib()
+    from rl_mpc_lanemerging_amd import control
+    g = load_golden("golden_default.npz")
+    for i in range(g["ego"].shape[0]):
+        x, y = g["ego"][i, 0], g["ego"][i, 1]
+        assert capi.ego_s(x, y) == g["ego"][i, 4]
+        assert control.get_ego_s((float(x), float(y))) == g["ego"][i, 4]
+    import rl_mpc_lanemerging_amd as pkg
+    snap = pkg.Settings.snapshot()
+    try:
+        pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+        p = capi.Params.from_settings(pkg.Settings)
+        assert capi.num_t(p) == g["t_values"].size == 18
+        for i in range(g["ego"].shape[0]):
+            assert capi.num_s(p, g["ego"][i, 4]) == g["num_s"][i]
+            sv = __import__("rl_mpc_lanemerging_amd").st.s_values_for(g["ego"][i, 4], p)
+            assert sv.size == g["num_s"][i]
+        pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+        p = capi.Params.from_settings(pkg.Settings)
+        assert capi.num_t(p) == 40 and capi.num_s(p, 0.0) == 7201
+    finally:
+        pkg.Settings.restore(snap)
+
+
+def test_settings_load_from_reference_style_json(tmp_path):
+    import json
+    import rl_mpc_lanemerging_amd as pkg
+    snap = pkg.Settings.snapshot()
+    try:
+        cfg = {"TASK": "ST", "S_DISCRETIZATION": 0.05, "T_DISCRETIZATION": 0.30, "FUTURE_S": 150.0, "FUTURE_T": 5.0,
+               "V_WEIGHT": 0.5, "A_WEIGHT": 10.0, "J_WEIGHT": 10.0, "D_WEIGHT": 10.0, "MIN_ALLOWED_DISTANCE": 5,
+               "CRASH_MIN_S": 20, "JERK_VALUES": {"0": -5, "1": 0}}
+        f = tmp_path / "st_low.json"
+        f.write_text(json.dumps(cfg))
+        pkg.Settings.load_from_file(str(f))
+        assert pkg.Settings.CRASH_MIN_S == 20 and pkg.Settings.TASK == "ST"
+        assert pkg.Settings.JERK_VALUES == {0: -5, 1: 0}        # dict keys cast to int (config.py:167-168)
+    finally:
+        pkg.Settings.restore(snap)
+        for k in ("TASK", "JERK_VALUES"):
+            if hasattr(pkg.Settings, k):
+                delattr(pkg.Settings, k)
+
+
+def test_mean_abs_jerk_matches_oracle():
+    capi = _lib()
+    from rl_mpc_lanemerging_amd import st
+    from oracle import st_oracle as orc
+    g = load_golden("golden_default.npz")
+    for i in range(0, 60):
+        bt = int(g["best_t"][i])
+        if bt < 2:
+            continue
+        seq = g["s_sequence"][i, :bt + 1]
+        a = st.get_path_mean_abs_jerk(seq, g["ego"][i, 2], g["ego"][i, 3], 0.3)
+        seqc = np.ascontiguousarray(seq)
+        b = orc.lib().orc_path_mean_abs_jerk(seqc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), seq.size,
+                                             g["ego"][i, 2], g["ego"][i, 3], 0.3)
+        c = capi.load().stmpc_path_mean_abs_jerk(seqc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), seq.size,
+                                                 g["ego"][i, 2], g["ego"][i, 3], 0.3)
+        assert a == b == c
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product must raise, never silently compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    capi = _lib()
+    with pytest.raises(capi.StmpcError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.STMPC_ENODEV
+
+
+def test_product_does_not_import_oracle():
+    pkgdir = os.path.join(REPO, "rl-mpc-lanemerging_amd")
+    for root, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("st_oracle.c header", ""), f
+    assert "oracle" not in open(os.path.join(REPO, "include", "stmpc.h")).read()
+
+
+def test_synth_generator_is_seeded_and_ordered():
+    from rl_mpc_lanemerging_amd import synth
+    a = synth.generate_states(64, seed=3)
+    b = synth.generate_states(64, seed=3)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ego, k, ox, ov = a
+    assert (np.diff(ox[:, :6], axis=1) < 0).all()            # front -> back
+    assert (ego[:, 2] - ego[:, 3] * 0.3 >= -1e-12).all()
