@@ -165,9 +165,11 @@ class Context:
         N = ego.shape[0]
         if ego.ndim != 2 or ego.shape[1] != 5:
             raise ValueError("ego must be [N,5] (x, y, v, a, start_s)")
-        other_x = np.ascontiguousarray(other_x, dtype=np.float64).reshape(N, -1)
-        other_v = np.ascontiguousarray(other_v, dtype=np.float64).reshape(N, -1)
-        Kmax = other_x.shape[1]
+        other_x = np.ascontiguousarray(other_x, dtype=np.float64)
+        other_v = np.ascontiguousarray(other_v, dtype=np.float64)
+        Kmax = other_x.shape[1] if other_x.ndim == 2 else (other_x.size // N if N else 0)
+        other_x = other_x.reshape(N, Kmax)
+        other_v = other_v.reshape(N, Kmax)
         H = num_t(params)
         path = np.empty((N, H), dtype=np.int32)
         best_t = np.empty(N, dtype=np.int32)
