@@ -69,10 +69,11 @@ typedef struct stmpc_params {
 typedef struct stmpc_stats {
     int64_t episodes;        /* N of the last batch */
     int64_t fast_path;       /* episodes finished by the LDS-resident kernel */
-    int64_t fallback;        /* episodes re-solved by the HBM-scratch kernel (window overflow) */
-    int64_t retries;         /* bound-tightening retries inside the fast kernel */
+    int64_t fallback;        /* episodes whose reachable span overflowed the first LDS window (re-solved in a larger one) */
+    int64_t hbm_tier;        /* of those, episodes that ended in the HBM-scratch tier */
+    int64_t retries;         /* reserved */
     double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
-    double  dp_kernel_ms;    /* device time of the lattice DP kernel alone */
+    double  dp_kernel_ms;    /* device time of the first-tier lattice DP kernel alone */
 } stmpc_stats;
 
 /* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */

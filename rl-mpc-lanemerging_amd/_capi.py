@@ -46,7 +46,7 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("episodes", C.c_int64), ("fast_path", C.c_int64), ("fallback", C.c_int64),
+    _fields_ = [("episodes", C.c_int64), ("fast_path", C.c_int64), ("fallback", C.c_int64), ("hbm_tier", C.c_int64),
                 ("retries", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
 
 

@@ -52,6 +52,12 @@ struct DevBuf {
 
 int next_pow2(int v) { int w = 1; while (w < v) w <<= 1; return w; }
 
+// divc<true> needs RN(1/d) to be usable by Markstein's theorem: excludes divisors whose significand is all ones
+bool fastdiv_ok(double d) {
+    uint64_t b; memcpy(&b, &d, 8);
+    return (d > 1e-100 && d < 1e100) && ((b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull);
+}
+
 }  // namespace
 
 struct stmpc_ctx {
@@ -59,7 +65,7 @@ struct stmpc_ctx {
     int num_cu = 256;
     int lds_per_block = 65536;
     // scratch
-    DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, overflow, bp, gscratch, bp_fb;
+    DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -71,8 +77,11 @@ struct stmpc_ctx {
     size_t pool_used = 0;          // events used (multiple of 4)
     double acc_solve_ms = 0, acc_dp_ms = 0;
     int64_t acc_launches = 0, acc_fallback = 0, acc_episodes = 0;
-    int fast_W = 1024;          // LDS window (cells) of the fast tier
-    int fast_blocks_per_cu = 5;
+    int lds_tier_W[STMPC_MAX_TIERS] = {1024, 4096, 0, 0};   // LDS windows (cells), increasing
+    int n_lds_tiers = 2;
+    int max_waves_per_cu = 16;
+    bool allow_fastdiv = true;
+    int last_nt = 0;
 };
 
 extern "C" {
@@ -117,8 +126,19 @@ int stmpc_create(stmpc_ctx **out, int device) {
         delete c;
         return fail(STMPC_EHIP, "hipEventCreate failed");
     }
-    const char *w = getenv("STMPC_FAST_W");
-    if (w) { int v = atoi(w); if (v >= 64 && v <= 4096 && (v & (v - 1)) == 0) c->fast_W = v; }
+    // experiment knobs: STMPC_TIERS="512,2048" (LDS windows), STMPC_WAVES_PER_CU, STMPC_FASTDIV=0
+    if (const char *w = getenv("STMPC_TIERS")) {
+        int n = 0; const char *q = w;
+        while (*q && n < STMPC_MAX_TIERS - 1) {
+            int v = atoi(q);
+            if (v >= 64 && v <= 8192 && (v & (v - 1)) == 0 && (n == 0 || v > c->lds_tier_W[n - 1])) c->lds_tier_W[n++] = v;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        if (n > 0) c->n_lds_tiers = n;
+    }
+    if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
+    if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     *out = c;
     return STMPC_OK;
 }
@@ -126,8 +146,8 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->overflow, &c->bp,
-                     &c->gscratch, &c->bp_fb, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
+    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->bp_tier[0],
+                     &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3};
     for (DevBuf *b : all) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -239,29 +259,37 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const int S_nom = stmpc_num_s(p, 0.0);
     if (S_nom < 2 || S_nom + 2 > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "number of position cells out of range");
     const int Kalloc = Kmax > 0 ? Kmax : 1;
+    const bool fastdiv = c->allow_fastdiv && fastdiv_ok(dp.dt) && fastdiv_ok(dp.dt2) && fastdiv_ok(dp.dt3);
 
     // scratch
     if ((rc = c->tab_edge.ensure((size_t)N * H * Kalloc * 2 * sizeof(double)))) return rc;
     if ((rc = c->tab_win.ensure((size_t)N * H * Kalloc * 2 * sizeof(int)))) return rc;
     if ((rc = c->tab_nact.ensure((size_t)N * H * sizeof(int)))) return rc;
     if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
-    if ((rc = c->counters.ensure(64))) return rc;
-    if ((rc = c->overflow.ensure((size_t)N * sizeof(int)))) return rc;
+    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
+    if ((rc = c->lists.ensure((size_t)STMPC_MAX_TIERS * N * sizeof(int)))) return rc;
 
-    const int W = c->fast_W;
-    const size_t lds_bytes = (size_t)W * 30;
-    int per_cu = (int)((size_t)(160 * 1024) / (lds_bytes + 512));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 16) per_cu = 16;
-    int grid_fast = c->num_cu * per_cu;
-    if (grid_fast > N) grid_fast = N;
-    if ((rc = c->bp.ensure((size_t)grid_fast * H * W * sizeof(u16)))) return rc;
-
+    // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2);
-    int grid_fb = c->num_cu * 4;
-    if (grid_fb > N) grid_fb = N;
-    if ((rc = c->gscratch.ensure((size_t)grid_fb * Wg * 30))) return rc;
-    if ((rc = c->bp_fb.ensure((size_t)grid_fb * H * Wg * sizeof(u16)))) return rc;
+    int tierW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS];
+    int nt = 0;
+    for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
+        int W = c->lds_tier_W[k];
+        if (W >= Wg && nt > 0) break;
+        if ((size_t)W * STMPC_CELL_BYTES + 1024 > (size_t)c->lds_per_block) break;
+        tierW[nt] = W; tierLds[nt] = true;
+        int per_cu = (int)((size_t)(c->lds_per_block) / ((size_t)W * STMPC_CELL_BYTES + 512));
+        if (per_cu > c->max_waves_per_cu) per_cu = c->max_waves_per_cu;
+        if (per_cu < 1) per_cu = 1;
+        tierGrid[nt] = c->num_cu * per_cu;
+        ++nt;
+    }
+    tierW[nt] = Wg; tierLds[nt] = false; tierGrid[nt] = c->num_cu * 8; ++nt;
+    for (int k = 0; k < nt; ++k) {
+        if (tierGrid[k] > N) tierGrid[k] = N;
+        if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * sizeof(u16)))) return rc;
+    }
+    if ((rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * Wg * STMPC_CELL_BYTES))) return rc;
 
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
@@ -281,23 +309,38 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
-    a.p = dp; a.N = N; a.Kmax = Kalloc; a.W = W; a.only_flagged = 0;
+    a.p = dp; a.N = N; a.Kmax = Kalloc;
     a.ego = d_ego; a.tab = tab;
-    a.bp = c->bp.as<u16>(); a.gscratch = nullptr; a.counters = counters; a.overflow_list = c->overflow.as<int>();
+    a.counters = counters; a.lists = c->lists.as<int>();
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIPCHK(hipEventRecord(e1, st));
-    hipLaunchKernelGGL((k_solve<true, false>), dim3(grid_fast), dim3(64), lds_bytes, st, a);
-    HIPCHK(hipEventRecord(e2, st));
-
-    // second tier: episodes whose reachable span overflowed the LDS window (list built on device)
-    SolveArgs b = a;
-    b.W = Wg; b.only_flagged = 1; b.bp = c->bp_fb.as<u16>(); b.gscratch = c->gscratch.as<unsigned char>();
-    hipLaunchKernelGGL((k_solve<false, false>), dim3(grid_fb), dim3(64), 0, st, b);
+    for (int k = 0; k < nt; ++k) {
+        a.W = tierW[k]; a.tier = k; a.last_tier = (k == nt - 1);
+        a.bp = c->bp_tier[k].as<u16>();
+        a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
+        const size_t lds = tierLds[k] ? (size_t)tierW[k] * STMPC_CELL_BYTES : 0;
+        const dim3 grid(tierGrid[k]), block(64);
+#define STMPC_LAUNCH(L, FD, KT_)                                                                              \
+        do {                                                                                                  \
+            if (lds > 48 * 1024)                                                                              \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_>,                          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_>), grid, block, lds, st, a);                        \
+        } while (0)
+        if (tierLds[k]) {
+            if (Kalloc <= 8) { if (fastdiv) STMPC_LAUNCH(true, true, 8); else STMPC_LAUNCH(true, false, 8); }
+            else { if (fastdiv) STMPC_LAUNCH(true, true, 0); else STMPC_LAUNCH(true, false, 0); }
+        } else {
+            if (fastdiv) STMPC_LAUNCH(false, true, 0); else STMPC_LAUNCH(false, false, 0);
+        }
+#undef STMPC_LAUNCH
+        if (k == 0) HIPCHK(hipEventRecord(e2, st));
+    }
     HIPCHK(hipEventRecord(e3, st));
     HIPCHK(hipGetLastError());
     c->stats.episodes = N;
+    c->last_nt = nt;
     c->stats_pending = !c->profiling;
     if (c->profiling) { c->acc_launches += 1; c->acc_episodes += N; }
     return STMPC_OK;
@@ -308,18 +351,19 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
     HIPCHK(hipSetDevice(c->device));
     if (c->stats_pending) {
         HIPCHK(hipEventSynchronize(c->ev3));
-        unsigned cnt[4] = {0, 0, 0, 0};
+        unsigned cnt[64];
         HIPCHK(hipMemcpy(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
         float ms_all = 0.f, ms_dp = 0.f;
         HIPCHK(hipEventElapsedTime(&ms_all, c->ev0, c->ev3));
         HIPCHK(hipEventElapsedTime(&ms_dp, c->ev1, c->ev2));
-        c->stats.fallback = cnt[1];
-        c->stats.fast_path = c->stats.episodes - cnt[1];
+        c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window
+        c->stats.hbm_tier = c->last_nt >= 2 ? cnt[4 * (c->last_nt - 1)] : 0;
+        c->stats.fast_path = c->stats.episodes - cnt[4];
         c->stats.retries = 0;
         c->stats.solve_ms = ms_all;
         c->stats.dp_kernel_ms = ms_dp;
         c->stats_pending = false;
-        if (cnt[3]) { *out = c->stats; return fail(STMPC_EINTERNAL, "solver error flag set on device"); }
+        if (cnt[STMPC_CNT_ERR]) { *out = c->stats; return fail(STMPC_EINTERNAL, "solver error flag set on device"); }
     }
     *out = c->stats;
     return STMPC_OK;
@@ -417,28 +461,28 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     if ((rc = c->s_misc1.ensure(cells * 8))) return rc;
     if ((rc = c->s_misc2.ensure((size_t)S * 8))) return rc;
     if ((rc = c->s_misc3.ensure((size_t)H * 8))) return rc;
-    if ((rc = c->counters.ensure(64))) return rc;
+    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     const int Wg = next_pow2(S + 2);
-    if ((rc = c->gscratch.ensure((size_t)Wg * 30))) return rc;
-    if ((rc = c->bp_fb.ensure((size_t)H * Wg * sizeof(u16)))) return rc;
+    if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES))) return rc;
+    if ((rc = c->bp_tier[STMPC_MAX_TIERS - 1].ensure((size_t)H * Wg * sizeof(u16)))) return rc;
     HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc2.p, s_values, (size_t)S * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(c->counters.p, 0, 64));
+    HIPCHK(hipMemset(c->counters.p, 0, 64 * sizeof(unsigned)));
     SolveArgs a;
     memset(&a, 0, sizeof a);
-    a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg;
+    a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.last_tier = 1;
     a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
-    a.bp = c->bp_fb.as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
+    a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
     a.s_sequence = c->s_misc3.as<double>();
-    hipLaunchKernelGGL((k_solve<false, true>), dim3(1), dim3(64), 0, nullptr, a);
+    hipLaunchKernelGGL((k_solve<false, true, false, 0>), dim3(1), dim3(64), 0, nullptr, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));
-    unsigned cnt[4];
+    unsigned cnt[64];
     HIPCHK(hipMemcpy(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
-    if (cnt[3]) return fail(STMPC_EINTERNAL, "grid solver reported a window overflow");
+    if (cnt[STMPC_CNT_ERR]) return fail(STMPC_EINTERNAL, "grid solver reported a window overflow");
     return STMPC_OK;
 }
 
@@ -460,7 +504,7 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     if ((rc = c->tab_win.ensure((size_t)H * Kalloc * 2 * 4))) return rc;
     if ((rc = c->tab_nact.ensure((size_t)H * 4))) return rc;
     if ((rc = c->tab_nums.ensure(4))) return rc;
-    if ((rc = c->counters.ensure(64))) return rc;
+    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     if ((rc = c->s_ego.ensure(5 * 8))) return rc;
     if ((rc = c->s_k.ensure(4))) return rc;
     if ((rc = c->s_ox.ensure((size_t)Kalloc * 8))) return rc;

@@ -185,9 +185,9 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 const int *__restrict__ k_count,
                                                 const double *__restrict__ other_x,
                                                 const double *__restrict__ other_v, CarTab tab,
-                                                unsigned *counters /* zeroed here: [0] work, [1] overflow count */) {
+                                                unsigned *counters /* [64], zeroed here */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0) { counters[0] = 0u; counters[1] = 0u; counters[2] = 0u; counters[3] = 0u; }
+    if (e < 64) counters[e] = 0u;
     if (e >= N) return;
     DState<KMAX> s;
     s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
@@ -275,12 +275,35 @@ __device__ __forceinline__ double dev_weighted_penalty(double d, double min_allo
     return d_w * pen;
 }
 
+// Correctly rounded x / d for a divisor whose correctly rounded reciprocal r = RN(1/d) is known:
+// q0 = RN(x*r) is within 1.5 ulp; one residual step makes it faithful, the second (Markstein's
+// theorem: faithful q, exact residual by FMA, r = RN(1/d)) gives RN(x/d).  5 ops instead of the
+// ~12 of the generic v_div_scale/v_rcp/v_div_fmas/v_div_fixup expansion.  The FMAs here are
+// explicit; nothing else in this file may contract (-ffp-contract=off).
+template <bool FASTDIV>
+__device__ __forceinline__ double divc(double x, double d, double r) {
+    if constexpr (FASTDIV) {
+        double q = x * r;
+        double e = __builtin_fma(-q, d, x);
+        q = __builtin_fma(e, r, q);
+        e = __builtin_fma(-q, d, x);
+        q = __builtin_fma(e, r, q);
+        return q;
+    } else {
+        return x / d;
+    }
+}
+
+#define STMPC_MAX_TIERS 4
+#define STMPC_CNT_ERR 63
+
 struct SolveArgs {
     DevP p;
     int N;
     int Kmax;
-    int W;                 // window cells (power of two)
-    int only_flagged;      // 0: pull episodes from counters[0]; 1: walk the overflow list
+    int W;                 // window cells of this tier (power of two)
+    int tier;              // 0: pull episodes 0..N-1 from counters[0]; k>=1: walk list k
+    int last_tier;         // overflow here is an internal error
     // table mode inputs
     const double *ego;     // [N][5]
     CarTab tab;
@@ -291,10 +314,10 @@ struct SolveArgs {
     int S_grid;
     double v0_grid, a0_grid;
     // scratch
-    u16 *bp;               // [slots][H][W] back-pointers
-    unsigned char *gscratch;   // global-storage variant: [slots][30*W] bytes
-    unsigned *counters;    // [0] work counter, [1] overflow count, [2] fallback work counter, [3] error flag
-    int *overflow_list;    // [N]
+    u16 *bp;               // [blocks][H][W] back-pointers of this tier
+    unsigned char *gscratch;   // HBM-storage variant: [blocks][20*W] bytes
+    unsigned *counters;    // [0] tier-0 work counter; [4k] list-k length, [4k+1] list-k work counter; [63] error flag
+    int *lists;            // [STMPC_MAX_TIERS][N] episode ids queued for tier k
     // outputs
     int *path_idx;         // [N][H]
     int *best_t;           // [N]
@@ -306,35 +329,19 @@ struct SolveArgs {
 
 template <bool USE_LDS>
 struct Mem {
-    static __device__ __forceinline__ u64 ld64(const u64 *p) {
-        if constexpr (USE_LDS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ void st64(u64 *p, u64 v) {
-        if constexpr (USE_LDS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ u64 min64(u64 *p, u64 v) {
-        if constexpr (USE_LDS) return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ u16 ld16(const u16 *p) {
-        if constexpr (USE_LDS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static __device__ __forceinline__ void st16(u16 *p, u16 v) {
-        if constexpr (USE_LDS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    static constexpr int SCOPE = USE_LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+    static __device__ __forceinline__ u64 ld64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ void st64(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ u64 min64(u64 *p, u64 v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ unsigned ld32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ void st32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
     static __device__ __forceinline__ double ldf(const double *p) {
-        if constexpr (USE_LDS) return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        else return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, __ATOMIC_RELAXED, SCOPE));
     }
     static __device__ __forceinline__ void stf(double *p, double v) {
-        if constexpr (USE_LDS) __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, SCOPE);
     }
-    // order this wave's own accesses: LDS is in-order per wave (compiler barrier suffices);
+    // order this wave's own accesses: LDS is in-order per wave (a compiler barrier suffices);
     // the HBM variant drains the vector-memory queue.
     static __device__ __forceinline__ void order() {
         if constexpr (USE_LDS) __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -343,9 +350,18 @@ struct Mem {
 };
 
 // Solve one episode with one wavefront.  Returns 0 ok, 1 window overflow.
-template <bool USE_LDS, bool GRID>
-__device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u64 *costB, double *pen,
-                             u16 *P0, u16 *P1, u16 *P2, int *path_lds) {
+//
+// Storage per lattice cell (circular, slot = cell & (W-1)):
+//   cost[]  u64  fp64 bits of the accumulated cost of the node, +inf bits = not reached
+//   hist[]  u32  (index of s_{t-1}) | (index of s_{t-2}) << 16 of the winning chain
+//   pen[]   f64  d_weight * distance_penalty of the cell in the layer being relaxed into, < 0 = blocked
+// ONE cost/hist array serves both the layer being expanded and the layer being built: sources are
+// consumed in DESCENDING chunks of 64 cells (loaded to registers first) and every edge goes to a
+// cell index >= its source (speeds are >= 0), so a target never lands on a source that is still
+// unread.  Live cells at any time lie in [wlo, ihi), which must fit in W.
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT>
+__device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, unsigned *hist, double *pen,
+                             int *path_lds) {
     typedef Mem<USE_LDS> M;
     const DevP &p = a.p;
     const int lane = threadIdx.x & 63;
@@ -361,18 +377,22 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
         s1 = start_s + p.ds; delta = s1 - start_s; S = a.tab.num_s[e];
     }
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
+    const double r_dt = 1.0 / dt, r_dt2 = 1.0 / dt2, r_dt3 = 1.0 / dt3, r_delta = 1.0 / delta;
     // st_cy.pyx:329-330 virtual history
     const double est_prev = start_s - v0 * dt;
     const double est_second = est_prev - dt * (v0 - a0 * dt);
+    const bool s1_plain = (start_s + 1.0 * delta == s1);      // numpy arange: a[1] = start+step, a[i>=2] = start+i*delta
     auto sval = [&](int n) -> double {
         if constexpr (GRID) return a.s_values[n];
-        else return (n == 1) ? s1 : start_s + (double)n * delta;     // numpy arange fill
+        else {
+            double v = start_s + (double)n * delta;
+            if (!s1_plain) { if (n == 1) v = s1; }
+            return v;
+        }
     };
     u16 *bp = a.bp + (size_t)slot * H * W;
 
-    u64 *cc = costA, *cn = costB;
-    u16 *Pprev = P0, *Pcur = P1, *Pnext = P2;
-    if (lane == 0) M::st64(&cc[0], 0ull);
+    if (lane == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); }
     M::order();
     int wlo = 0, whi = 1;
     int best_t = 0, best_n = 0;
@@ -385,8 +405,10 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
         u64 my_best = ~0ull;
         int my_best_n = 0x7fffffff;
         int n_active = 0;
-        // obstructing vehicles of layer t+1 (wave-uniform)
+        // obstructing vehicles of layer t+1 (wave-uniform): kept in SGPRs when KT > 0
         int nact = 0;
+        double cfront[KT > 0 ? KT : 1], cback[KT > 0 ? KT : 1];
+        int cimin[KT > 0 ? KT : 1], cimax[KT > 0 ? KT : 1];
         const double *cedge = nullptr;
         const int *cwin = nullptr;
         if constexpr (!GRID) {
@@ -395,6 +417,16 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
                 nact = a.tab.nact[row];
                 cedge = a.tab.edge + row * a.Kmax * 2;
                 cwin = a.tab.win + row * a.Kmax * 2;
+                if constexpr (KT > 0) {
+                    // lane c loads vehicle c, then broadcast to scalars
+                    double f = 0.0, b = 0.0; int i0 = 0, i1 = 0;
+                    if (lane < nact) { f = cedge[lane * 2]; b = cedge[lane * 2 + 1]; i0 = cwin[lane * 2]; i1 = cwin[lane * 2 + 1]; }
+#pragma unroll
+                    for (int c = 0; c < KT; ++c) {
+                        cfront[c] = __shfl(f, c); cback[c] = __shfl(b, c);
+                        cimin[c] = __shfl(i0, c); cimax[c] = __shfl(i1, c);
+                    }
+                }
             }
         }
         auto init_cells = [&](int from, int to) {
@@ -407,24 +439,37 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
                 } else {
                     double d = 1e10;                                         // st.py:34-35
                     bool blocked = false;
-                    for (int c = 0; c < nact; ++c) {
-                        double f = fabs(sn - cedge[c * 2 + 0]);
-                        double b = fabs(sn - cedge[c * 2 + 1]);
-                        d = (f < d) ? f : d; d = (b < d) ? b : d;            // st.py:56-57
-                        blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);   // st.py:64
+                    if constexpr (KT > 0) {
+#pragma unroll
+                        for (int c = 0; c < KT; ++c) {
+                            if (c < nact) {
+                                double f = fabs(sn - cfront[c]);
+                                double b = fabs(sn - cback[c]);
+                                d = (f < d) ? f : d; d = (b < d) ? b : d;    // st.py:56-57
+                                blocked |= (n >= cimin[c]) & (n < cimax[c]); // st.py:64
+                            }
+                        }
+                    } else {
+                        for (int c = 0; c < nact; ++c) {
+                            double f = fabs(sn - cedge[c * 2 + 0]);
+                            double b = fabs(sn - cedge[c * 2 + 1]);
+                            d = (f < d) ? f : d; d = (b < d) ? b : d;
+                            blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
+                        }
                     }
                     pv = blocked ? -1.0 : dev_weighted_penalty(d, p.min_allowed, p.d_w);
                 }
                 M::stf(&pen[n & WM], pv);
-                M::st64(&cn[n & WM], INF_BITS);
+                M::st64(&cost[n & WM], INF_BITS);
             }
             M::order();
         };
 
-        for (int base = wlo; base < whi; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < whi;
-            const u64 cb = valid ? M::ld64(&cc[i & WM]) : INF_BITS;
+        // sources of layer t, highest cells first
+        for (int top = whi; top > wlo; top -= 64) {
+            const int i = top - 64 + lane;
+            const bool valid = i >= wlo;
+            const u64 cb = valid ? M::ld64(&cost[i & WM]) : INF_BITS;
             const bool act = cb < INF_BITS;
             const u64 amask = __ballot(act);
             if (!amask) continue;
@@ -432,22 +477,24 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
             double sv = 0.0, p1 = 0.0, p2 = 0.0;
             const double C = __longlong_as_double((long long)cb);
             int lo = 0, hi = 0;
+            unsigned myh = 0u;        // what a target won by this source stores: i | (p1 index << 16)
             if (act) {
-                if (cb < my_best) { my_best = cb; my_best_n = i; }
+                if (cb < my_best || (cb == my_best && i < my_best_n)) { my_best = cb; my_best_n = i; }
                 sv = sval(i);
-                if (t == 0) { p1 = est_prev; p2 = est_second; }              // st_cy.pyx:342
+                if (t == 0) { p1 = est_prev; p2 = est_second; myh = 0u; }      // st_cy.pyx:342
                 else {
-                    int pr = M::ld16(&Pcur[i & WM]);
+                    const unsigned h = M::ld32(&hist[i & WM]);
+                    const int pr = (int)(h & 0xFFFFu), pp = (int)(h >> 16);
                     bp[(size_t)t * W + (i & WM)] = (u16)pr;
                     p1 = sval(pr);
-                    if (t == 1) p2 = est_prev;
-                    else { int pp = M::ld16(&Pprev[pr & WM]); p2 = sval(pp); }
+                    p2 = (t == 1) ? est_prev : sval(pp);
+                    myh = (unsigned)i | ((unsigned)pr << 16);
                 }
                 if (relax) {
                     // st_cy.pyx:65-75
-                    double prev_v = (p1 - p2) / dt;
-                    double v = (sv - p1) / dt;
-                    double acc = (v - prev_v) / dt;
+                    double prev_v = divc<FASTDIV>(p1 - p2, dt, r_dt);
+                    double v = divc<FASTDIV>(sv - p1, dt, r_dt);
+                    double acc = divc<FASTDIV>(v - prev_v, dt, r_dt);
                     double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
                     double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
                     double min_v = dmax_py(v + min_a * dt, 0.0);
@@ -455,26 +502,29 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
                     double min_s = sv + min_v * dt;
                     double max_s = sv + max_v * dt;
                     // st_cy.pyx:78-93
-                    double x = (min_s - start_s) / delta;
+                    double x = divc<FASTDIV>(min_s - start_s, delta, r_delta);
                     int mi = (int)x;
-                    int ma = (int)((max_s - start_s) / delta);
+                    int ma = (int)divc<FASTDIV>(max_s - start_s, delta, r_delta);
                     if (mi < x) mi += 1;
                     lo = mi; hi = ma + 1;
                     if (hi > S) hi = S;                                      // st_cy.pyx:379
+                    if (lo < i) lo = i;                                      // cannot happen (min_v >= 0); keeps the in-place invariant
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
             }
+            M::order();      // this chunk's cost/hist are in registers: its cells may now be overwritten
             if (!relax) continue;
             const int clo = wave_min_i(hi > lo ? lo : 0x7fffffff), chi = wave_max_i(hi);
             if (clo >= chi) continue;
             const int fan = wave_max_i(hi > lo ? hi - lo : 0);
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
-            if (nhi2 - nlo2 > W) return 1;                                   // reachable span exceeds the window
+            if (nhi2 - wlo > W) return 1;                                    // live cells [wlo, nhi2) exceed the window
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
 
+            const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
             for (int c = 0; c < fan; ++c) {
                 const int n = lo + c;
                 bool tie = false;
@@ -485,18 +535,18 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
                     if (pn >= 0.0) {                                         // st_cy.pyx:383 obstacle skip
                         const double sn = sval(n);
                         // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
-                        const double v = (sn - sv) / dt;
-                        const double aa = (sn - 2 * sv + p1) / dt2;
-                        const double jj = (sn - 3 * sv + 3 * p1 - p2) / dt3;
+                        const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
+                        const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
+                        const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
                         const double dv = v - p.v_des;
                         const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn;
                         const double tot = C + ec;                           // st_cy.pyx:388
                         const u64 tb = (u64)__double_as_longlong(tot);
-                        const u64 old = M::min64(&cn[sl], tb);
+                        const u64 old = M::min64(&cost[sl], tb);
                         M::order();
-                        const u64 cur = M::ld64(&cn[sl]);
+                        const u64 cur = M::ld64(&cost[sl]);
                         if (cur == tb) {
-                            if (old > tb) M::st16(&Pnext[sl], (u16)i);       // unique first setter of this value
+                            if (old > tb) M::st32(&hist[sl], myh);           // unique first setter of this value
                             else tie = true;                                 // equal cost already present
                         }
                     }
@@ -507,7 +557,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
                 while (tm) {
                     const int l = __ffsll((long long)tm) - 1;
                     tm &= tm - 1;
-                    if (lane == l) { u16 q = M::ld16(&Pnext[sl]); if ((u16)i < q) M::st16(&Pnext[sl], (u16)i); }
+                    if (lane == l) { unsigned q = M::ld32(&hist[sl]); if ((unsigned)i < (q & 0xFFFFu)) M::st32(&hist[sl], myh); }
                     M::order();
                 }
             }
@@ -517,8 +567,6 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
         best_t = t; best_n = my_best_n; best_bits = my_best;
         if (!relax) break;
         if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
-        u64 *tc = cc; cc = cn; cn = tc;
-        u16 *tp = Pprev; Pprev = Pcur; Pcur = Pnext; Pnext = tp;
     }
 
     // back-track (st_cy.pyx:391-398)
@@ -584,28 +632,30 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *costA, u6
     return 0;
 }
 
-// Persistent kernel: blocks of one wave pull episodes until the batch is done.
-template <bool USE_LDS, bool GRID>
+#define STMPC_CELL_BYTES 20     // cost 8 + pen 8 + hist 4
+
+// Persistent kernel: blocks of one wave pull episodes until the tier's queue is drained.
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT>
 __global__ void __launch_bounds__(64) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int path_lds[STMPC_MAXH];
     const int lane = threadIdx.x;
     const int W = a.W;
-    u64 *costA, *costB; double *pen; u16 *P0, *P1, *P2;
     unsigned char *base;
     if constexpr (USE_LDS) base = smem;
-    else base = a.gscratch + (size_t)blockIdx.x * (size_t)W * 30;
-    costA = (u64 *)base; costB = costA + W; pen = (double *)(costB + W);
-    P0 = (u16 *)(pen + W); P1 = P0 + W; P2 = P1 + W;
+    else base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES;
+    u64 *cost = (u64 *)base;
+    double *pen = (double *)(cost + W);
+    unsigned *hist = (unsigned *)(pen + W);
 
     if constexpr (GRID) {
-        int rc = solve_episode<USE_LDS, true>(a, 0, 0, costA, costB, pen, P0, P1, P2, path_lds);
-        if (rc != 0 && lane == 0) atomicExch(&a.counters[3], 1u);
+        int rc = solve_episode<USE_LDS, true, FASTDIV, 0>(a, 0, 0, cost, hist, pen, path_lds);
+        if (rc != 0 && lane == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
         for (;;) {
             int e;
-            if (!a.only_flagged) {
+            if (a.tier == 0) {
                 unsigned w = 0;
                 if (lane == 0) w = atomicAdd(&a.counters[0], 1u);
                 w = __builtin_amdgcn_readfirstlane(w);
@@ -614,21 +664,21 @@ __global__ void __launch_bounds__(64) k_solve(SolveArgs a) {
             } else {
                 unsigned w = 0, cnt = 0;
                 if (lane == 0) {
-                    w = atomicAdd(&a.counters[2], 1u);
-                    cnt = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
+                    cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 w = __builtin_amdgcn_readfirstlane(w);
                 cnt = __builtin_amdgcn_readfirstlane(cnt);
                 if (w >= cnt) break;
-                e = a.overflow_list[w];
+                e = a.lists[(size_t)a.tier * a.N + w];
             }
-            int rc = solve_episode<USE_LDS, false>(a, e, blockIdx.x, costA, costB, pen, P0, P1, P2, path_lds);
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT>(a, e, blockIdx.x, cost, hist, pen, path_lds);
             if (rc != 0 && lane == 0) {
-                if (!a.only_flagged) {
-                    unsigned pos = atomicAdd(&a.counters[1], 1u);
-                    a.overflow_list[pos] = e;
+                if (!a.last_tier) {
+                    unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
+                    a.lists[(size_t)(a.tier + 1) * a.N + pos] = e;
                 } else {
-                    atomicExch(&a.counters[3], 1u);   // the HBM variant's window covers all S cells: cannot happen
+                    atomicExch(&a.counters[STMPC_CNT_ERR], 1u);   // the last tier's window covers all S cells
                 }
             }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -670,6 +720,7 @@ __global__ void k_probe(int op, const double *a, const double *b, double *out, i
         case 1: r = sqrt(x); break;
         case 2: r = x * y; break;
         case 3: r = x + y; break;
+        case 5: r = divc<true>(x, y, 1.0 / y); break;
         default: r = __builtin_fma(x, x, y * y); break;
     }
     out[i] = r;

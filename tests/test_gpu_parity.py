@@ -31,10 +31,15 @@ def test_device_arithmetic_is_ieee(gpu_ctx):
     assert np.array_equal(gpu_ctx.probe_arith(1, np.abs(a)), np.sqrt(np.abs(a)))
     assert np.array_equal(gpu_ctx.probe_arith(2, a, b), a * b)
     assert np.array_equal(gpu_ctx.probe_arith(3, a, b), a + b)
-    # divisions by the lattice constants
-    for d in (0.3, 0.3 * 0.3, 0.3 ** 3, 0.05, 0.05000000000000071, 0.2):
+    # divisions by the lattice constants: generic IEEE division and the 5-op constant division (divc<true>)
+    for d in (0.3, 0.3 * 0.3, 0.3 ** 3, 0.05, 0.05000000000000071, 0.2, 0.2 ** 3, 0.1, 0.25, 0.5 ** 3):
         bb = np.full(n, d)
         assert np.array_equal(gpu_ctx.probe_arith(0, a, bb), a / bb)
+        assert np.array_equal(gpu_ctx.probe_arith(5, a, bb), a / bb)
+    # and by per-episode lattice steps delta_s = s_values[1] - s_values[0]
+    s0 = rng.uniform(-260, 120, n)
+    delta = (s0 + 0.05) - s0
+    assert np.array_equal(gpu_ctx.probe_arith(5, a, delta), a / delta)
 
 
 @pytest.mark.parametrize("fname", STATE_FILES)
@@ -50,19 +55,23 @@ def test_batch_matches_reference_golden(fname, gpu_ctx, restore_settings):
         assert np.array_equal(seq, g["s_sequence"][i])
 
 
-@pytest.mark.parametrize("wcells", [64, 256, 1024])
-def test_window_overflow_falls_back_exactly(wcells, restore_settings, monkeypatch):
-    """Tiny LDS windows force most episodes through the HBM-scratch tier: results must not change."""
+@pytest.mark.parametrize("tiers", ["64", "256,512", "512,2048", "64,128,256"])
+@pytest.mark.parametrize("fastdiv", ["1", "0"])
+def test_window_overflow_falls_back_exactly(tiers, fastdiv, restore_settings, monkeypatch):
+    """Tiny LDS windows force episodes through the larger-window / HBM-scratch tiers: results must not
+    change; neither may they change between the 5-op constant division and the generic IEEE division."""
     from rl_mpc_lanemerging_amd import _capi, st
-    monkeypatch.setenv("STMPC_FAST_W", str(wcells))
+    monkeypatch.setenv("STMPC_TIERS", tiers)
+    monkeypatch.setenv("STMPC_FASTDIV", fastdiv)
     ctx = _capi.Context(0)
     g = load_golden("golden_default.npz")
     p, op = settings_from_golden(g)
     res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
     _check(res, g, g["t_values"].size)
     s = ctx.stats()
-    if wcells <= 256:
-        assert s["fallback"] > 0
+    assert s["fallback"] > 0
+    if tiers == "64":
+        assert s["hbm_tier"] == s["fallback"]
     ctx.close()
 
 
