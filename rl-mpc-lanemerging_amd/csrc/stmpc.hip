@@ -270,7 +270,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if ((rc = c->lists.ensure((size_t)STMPC_MAX_TIERS * N * sizeof(int)))) return rc;
 
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
-    const int Wg = next_pow2(S_nom + 2);
+    const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack
     int tierW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS];
     int nt = 0;
     for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
@@ -462,7 +462,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     if ((rc = c->s_misc2.ensure((size_t)S * 8))) return rc;
     if ((rc = c->s_misc3.ensure((size_t)H * 8))) return rc;
     if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
-    const int Wg = next_pow2(S + 2);
+    const int Wg = next_pow2(S + 2 + 128);
     if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES))) return rc;
     if ((rc = c->bp_tier[STMPC_MAX_TIERS - 1].ensure((size_t)H * Wg * sizeof(u16)))) return rc;
     HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));

@@ -47,16 +47,25 @@ struct DevP {
 __device__ __forceinline__ double dmin_py(double a, double b) { return (b < a) ? b : a; }   // Python/Cython min(a,b)
 __device__ __forceinline__ double dmax_py(double a, double b) { return (b > a) ? b : a; }   // Python/Cython max(a,b)
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = (w < v) ? w : v; }
-    return v;
+// Wave-wide integer min / max on the DPP network (no LDS round trips): row_shr 1,2,4,8 leave each
+// 16-lane row's result in its last lane, row_bcast:15 / row_bcast:31 fold the rows, lane 63 holds the result.
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_reduce_i(int v) {
+    const int ident = IS_MIN ? 0x7fffffff : (int)0x80000000;
+#define STMPC_DPP_STEP(CTRL, RMASK)                                                              \
+    { int t_ = __builtin_amdgcn_update_dpp(ident, v, CTRL, RMASK, 0xf, false);                   \
+      v = IS_MIN ? (t_ < v ? t_ : v) : (t_ > v ? t_ : v); }
+    STMPC_DPP_STEP(0x111, 0xf)   // row_shr:1
+    STMPC_DPP_STEP(0x112, 0xf)   // row_shr:2
+    STMPC_DPP_STEP(0x114, 0xf)   // row_shr:4
+    STMPC_DPP_STEP(0x118, 0xf)   // row_shr:8
+    STMPC_DPP_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1,3
+    STMPC_DPP_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2,3
+#undef STMPC_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = (w > v) ? w : v; }
-    return v;
-}
+__device__ __forceinline__ int wave_min_i(int v) { return wave_reduce_i<true>(v); }
+__device__ __forceinline__ int wave_max_i(int v) { return wave_reduce_i<false>(v); }
 // lexicographic min of (bits, n) across the wave
 __device__ __forceinline__ void wave_min_key(u64 &bits, int &n) {
 #pragma unroll
@@ -431,12 +440,15 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
         }
         auto init_cells = [&](int from, int to) {
             for (int n = from + lane; n < to; n += 64) {
-                double sn = sval(n);
                 double pv;
                 if constexpr (GRID) {
-                    size_t at = (size_t)(t + 1) * S + n;
-                    pv = a.obstacles[at] ? -1.0 : dev_weighted_penalty(a.distances[at], p.min_allowed, p.d_w);
+                    pv = -1.0;
+                    if (n < S) {
+                        size_t at = (size_t)(t + 1) * S + n;
+                        if (!a.obstacles[at]) pv = dev_weighted_penalty(a.distances[at], p.min_allowed, p.d_w);
+                    }
                 } else {
+                    const double sn = sval(n);
                     double d = 1e10;                                         // st.py:34-35
                     bool blocked = false;
                     if constexpr (KT > 0) {
@@ -466,9 +478,9 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
         };
 
         // sources of layer t, highest cells first
-        for (int top = whi; top > wlo; top -= 64) {
+        for (int top = (whi + 63) & ~63; top > wlo; top -= 64) {      // chunks aligned to multiples of 64 cells
             const int i = top - 64 + lane;
-            const bool valid = i >= wlo;
+            const bool valid = (i >= wlo) & (i < whi);
             const u64 cb = valid ? M::ld64(&cost[i & WM]) : INF_BITS;
             const bool act = cb < INF_BITS;
             const u64 amask = __ballot(act);
@@ -514,22 +526,25 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
             }
             M::order();      // this chunk's cost/hist are in registers: its cells may now be overwritten
             if (!relax) continue;
-            const int clo = wave_min_i(hi > lo ? lo : 0x7fffffff), chi = wave_max_i(hi);
+            int clo = wave_min_i(hi > lo ? lo : 0x7fffffff), chi = wave_max_i(hi);
             if (clo >= chi) continue;
-            const int fan = wave_max_i(hi > lo ? hi - lo : 0);
+            // the interval of initialised next-layer cells grows in whole 64-cell blocks: clo >= top-64 (a
+            // multiple of 64), so rounding down never touches a source that is still unread
+            clo &= ~63; chi = (chi + 63) & ~63;
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
-            if (nhi2 - wlo > W) return 1;                                    // live cells [wlo, nhi2) exceed the window
+            if (nhi2 - (wlo & ~63) > W) return 1;                            // live cells exceed the circular window
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
-            for (int c = 0; c < fan; ++c) {
+            for (int c = 0;; ++c) {
                 const int n = lo + c;
+                if (!__ballot(n < hi)) break;                                // inactive lanes have lo = hi = 0
                 bool tie = false;
                 int sl = 0;
-                if (act && n < hi) {
+                if (n < hi) {
                     sl = n & WM;
                     const double pn = M::ldf(&pen[sl]);
                     if (pn >= 0.0) {                                         // st_cy.pyx:383 obstacle skip
