@@ -71,7 +71,9 @@ typedef struct stmpc_stats {
     int64_t fast_path;       /* episodes finished by the LDS-resident kernel */
     int64_t fallback;        /* episodes whose reachable span overflowed the first LDS window (re-solved in a larger one) */
     int64_t hbm_tier;        /* of those, episodes that ended in the HBM-scratch tier */
-    int64_t retries;         /* reserved */
+    int64_t retries;         /* exact passes repeated because the pre-pass bound was below the reference's terminal cost */
+    int64_t nodes_exact;     /* lattice nodes expanded by the exact passes (all tiers, incl. repeated work) */
+    int64_t nodes_bound;     /* lattice nodes expanded by the bounding pre-passes */
     double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
     double  dp_kernel_ms;    /* device time of the first-tier lattice DP kernel alone */
 } stmpc_stats;

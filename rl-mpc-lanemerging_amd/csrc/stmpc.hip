@@ -77,10 +77,13 @@ struct stmpc_ctx {
     size_t pool_used = 0;          // events used (multiple of 4)
     double acc_solve_ms = 0, acc_dp_ms = 0;
     int64_t acc_launches = 0, acc_fallback = 0, acc_episodes = 0;
-    int lds_tier_W[STMPC_MAX_TIERS] = {1024, 4096, 0, 0};   // LDS windows (cells), increasing
+    int lds_tier_W[STMPC_MAX_TIERS] = {2048, 4096, 0, 0};   // LDS windows (cells), increasing
     int n_lds_tiers = 2;
     int max_waves_per_cu = 16;
+    int waves_override = 0;       // STMPC_NW: waves per workgroup (episode) for every tier
     bool allow_fastdiv = true;
+    bool prune = true;
+    double band_override = 0.0;
     int last_nt = 0;
 };
 
@@ -138,7 +141,10 @@ int stmpc_create(stmpc_ctx **out, int device) {
         if (n > 0) c->n_lds_tiers = n;
     }
     if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
+    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) c->waves_override = v; }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
     *out = c;
     return STMPC_OK;
 }
@@ -269,22 +275,33 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     if ((rc = c->lists.ensure((size_t)STMPC_MAX_TIERS * N * sizeof(int)))) return rc;
 
+    // widest fan-out the dynamics allow (st_cy.pyx:65-93): acceleration- or jerk-limited window, +2 for rounding
+    const double fan_acc = (dp.a_max - dp.a_min) * dp.dt2 / dp.ds, fan_jerk = (dp.j_max - dp.j_min) * dp.dt3 / dp.ds;
+    const double fan_bound = (fan_acc < fan_jerk ? fan_acc : fan_jerk) + 2.0;
+    const bool small_fan = fan_bound <= 8.0;
+
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack
-    int tierW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS];
+    int tierW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS]; int tierNW[STMPC_MAX_TIERS];
+    size_t tierLdsBytes[STMPC_MAX_TIERS];
     int nt = 0;
     for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
         int W = c->lds_tier_W[k];
         if (W >= Wg && nt > 0) break;
-        if ((size_t)W * STMPC_CELL_BYTES + 1024 > (size_t)c->lds_per_block) break;
-        tierW[nt] = W; tierLds[nt] = true;
-        int per_cu = (int)((size_t)(c->lds_per_block) / ((size_t)W * STMPC_CELL_BYTES + 512));
-        if (per_cu > c->max_waves_per_cu) per_cu = c->max_waves_per_cu;
+        const size_t lds = (size_t)W * STMPC_CELL_BYTES + stmpc_chunk_ints(W) * sizeof(int);
+        if (lds + 2048 > (size_t)c->lds_per_block) break;
+        tierW[nt] = W; tierLds[nt] = true; tierLdsBytes[nt] = lds;
+        tierNW[nt] = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
+        int per_cu = (int)((size_t)(c->lds_per_block) / (lds + 1024));
+        int by_waves = c->max_waves_per_cu / tierNW[nt];
+        if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
         tierGrid[nt] = c->num_cu * per_cu;
         ++nt;
     }
-    tierW[nt] = Wg; tierLds[nt] = false; tierGrid[nt] = c->num_cu * 8; ++nt;
+    tierW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
+    tierLdsBytes[nt] = stmpc_chunk_ints(Wg) * sizeof(int);
+    tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     for (int k = 0; k < nt; ++k) {
         if (tierGrid[k] > N) tierGrid[k] = N;
         if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * sizeof(u16)))) return rc;
@@ -312,6 +329,10 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.p = dp; a.N = N; a.Kmax = Kalloc;
     a.ego = d_ego; a.tab = tab;
     a.counters = counters; a.lists = c->lists.as<int>();
+    a.prune = c->prune ? 1 : 0;
+    // band of the bounding pre-pass: a quarter of the per-step cost of standing still (112.5 with the
+    // reference's weights); any value is safe (the exact pass re-checks), it only trades pre-pass work for tightness
+    a.band = c->band_override > 0 ? c->band_override : fmax(1.0, 0.25 * dp.v_w * dp.v_des * dp.v_des);
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
     HIPCHK(hipEventRecord(e1, st));
@@ -319,21 +340,23 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.W = tierW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
-        const size_t lds = tierLds[k] ? (size_t)tierW[k] * STMPC_CELL_BYTES : 0;
-        const dim3 grid(tierGrid[k]), block(64);
-#define STMPC_LAUNCH(L, FD, KT_)                                                                              \
+        const size_t lds = tierLdsBytes[k];
+        const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
+#define STMPC_LAUNCH(L, FD, KT_, FM)                                                                          \
         do {                                                                                                  \
             if (lds > 48 * 1024)                                                                              \
-                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_>,                          \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM>,                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            hipLaunchKernelGGL((k_solve<L, false, FD, KT_>), grid, block, lds, st, a);                        \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM>), grid, block, lds, st, a);                    \
         } while (0)
+#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 16); } while (0)
         if (tierLds[k]) {
-            if (Kalloc <= 8) { if (fastdiv) STMPC_LAUNCH(true, true, 8); else STMPC_LAUNCH(true, false, 8); }
-            else { if (fastdiv) STMPC_LAUNCH(true, true, 0); else STMPC_LAUNCH(true, false, 0); }
+            if (Kalloc <= 8) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
+            else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }
         } else {
-            if (fastdiv) STMPC_LAUNCH(false, true, 0); else STMPC_LAUNCH(false, false, 0);
+            if (fastdiv) STMPC_LAUNCH_FM(false, true, 0); else STMPC_LAUNCH_FM(false, false, 0);
         }
+#undef STMPC_LAUNCH_FM
 #undef STMPC_LAUNCH
         if (k == 0) HIPCHK(hipEventRecord(e2, st));
     }
@@ -359,7 +382,9 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window
         c->stats.hbm_tier = c->last_nt >= 2 ? cnt[4 * (c->last_nt - 1)] : 0;
         c->stats.fast_path = c->stats.episodes - cnt[4];
-        c->stats.retries = 0;
+        c->stats.retries = cnt[STMPC_CNT_RETRY];
+        c->stats.nodes_exact = cnt[STMPC_CNT_NODES_EXACT];
+        c->stats.nodes_bound = cnt[STMPC_CNT_NODES_BOUND];
         c->stats.solve_ms = ms_all;
         c->stats.dp_kernel_ms = ms_dp;
         c->stats_pending = false;
@@ -476,7 +501,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
     a.s_sequence = c->s_misc3.as<double>();
-    hipLaunchKernelGGL((k_solve<false, true, false, 0>), dim3(1), dim3(64), 0, nullptr, a);
+    hipLaunchKernelGGL((k_solve<false, true, false, 0, 16>), dim3(1), dim3(256), stmpc_chunk_ints(Wg) * sizeof(int), nullptr, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));

@@ -280,8 +280,11 @@ __global__ void __launch_bounds__(64) k_predict_step(DevP p, int mode, int N, in
 // ---------------------------------------------------------------- lattice DP
 // st_cy.pyx:34-38 distance_penalty, pre-multiplied by d_weight exactly as st_cy.pyx:50 does
 __device__ __forceinline__ double dev_weighted_penalty(double d, double min_allowed, double d_w) {
-    double pen = (d < min_allowed) ? (1000000.0 / dmax_py(d, 1.0)) : (1 / d);
-    return d_w * pen;
+    // one IEEE division either way: 1000000.0 / max(d, 1.0) or 1 / d
+    const bool close = d < min_allowed;
+    const double num = close ? 1000000.0 : 1.0;
+    const double den = close ? dmax_py(d, 1.0) : d;
+    return d_w * (num / den);
 }
 
 // Correctly rounded x / d for a divisor whose correctly rounded reciprocal r = RN(1/d) is known:
@@ -305,6 +308,9 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
 
 #define STMPC_MAX_TIERS 4
 #define STMPC_CNT_ERR 63
+#define STMPC_CNT_RETRY 62
+#define STMPC_CNT_NODES_EXACT 61
+#define STMPC_CNT_NODES_BOUND 60
 
 struct SolveArgs {
     DevP p;
@@ -313,6 +319,8 @@ struct SolveArgs {
     int W;                 // window cells of this tier (power of two)
     int tier;              // 0: pull episodes 0..N-1 from counters[0]; k>=1: walk list k
     int last_tier;         // overflow here is an internal error
+    int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
+    double band;           // cost band of the pre-pass
     // table mode inputs
     const double *ego;     // [N][5]
     CarTab tab;
@@ -344,6 +352,9 @@ struct Mem {
     static __device__ __forceinline__ u64 min64(u64 *p, u64 v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, SCOPE); }
     static __device__ __forceinline__ unsigned ld32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
     static __device__ __forceinline__ void st32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ unsigned min32(unsigned *p, unsigned v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ u16 ld16(const u16 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ void st16(u16 *p, u16 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
     static __device__ __forceinline__ double ldf(const double *p) {
         return __longlong_as_double((long long)__hip_atomic_load((const u64 *)p, __ATOMIC_RELAXED, SCOPE));
     }
@@ -358,63 +369,116 @@ struct Mem {
     }
 };
 
-// Solve one episode with one wavefront.  Returns 0 ok, 1 window overflow.
+// Per-episode constants shared by the passes of one solve.
+struct Ep {
+    double start_s, s1, delta, v0, a0;
+    double r_dt, r_dt2, r_dt3, r_delta, est_prev, est_second;
+    int S, e;
+    bool s1_plain;
+    u16 *bp;
+};
+
+struct PassOut {
+    int best_t, best_n;
+    u64 best_bits;
+    bool pruned;       // some reached node was not expanded (bound / band) or some cell was withheld
+    int nodes;         // expanded nodes
+};
+
+// Workgroup-shared scratch of one episode (LDS in every variant).
+#define STMPC_MAXWAVES 16
+struct WgShared {
+    int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
+    u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
+    int best_n[STMPC_MAXWAVES];
+    u64 min_tot[STMPC_MAXWAVES];          // per-wave cheapest relaxed candidate (PASS_BOUND)
+    int flags;                            // bit 0: a reached node was not expanded
+    int nlist;
+    int work;                             // episode id broadcast / -1 = queue drained
+    int rc;
+    int path[STMPC_MAXH];
+};
+
+enum { PASS_EXACT = 0, PASS_BOUND = 1 };
+
+// One forward sweep over the layers by one WORKGROUP of NW wavefronts.  Returns 0 ok, 1 window overflow
+// (workgroup-uniform).
+//
+// PASS_EXACT: the reference's search restricted to nodes whose cost is <= ubits.  Every node with true
+//   cost <= the bound gets exactly the reference's (cost, predecessor, history): all of its ancestors
+//   cost less, so none of them was cut, and any cut node could only offer candidates above the bound.
+//   With ubits = +inf bits this is the full layered DP.
+// PASS_BOUND: cheap search for an upper bound of the terminal cost: expands only nodes within `band` of
+//   the cheapest node of their layer and (hardsoft) treats cells closer than min_allowed to a vehicle as
+//   blocked; no back-pointers, no tie repair.  Any complete path it finds is a valid bound.
 //
 // Storage per lattice cell (circular, slot = cell & (W-1)):
 //   cost[]  u64  fp64 bits of the accumulated cost of the node, +inf bits = not reached
-//   hist[]  u32  (index of s_{t-1}) | (index of s_{t-2}) << 16 of the winning chain
+//   hist[]  u32  (index of s_{t-1}) << 16 | (index of s_{t-2}) of the winning chain
 //   pen[]   f64  d_weight * distance_penalty of the cell in the layer being relaxed into, < 0 = blocked
-// ONE cost/hist array serves both the layer being expanded and the layer being built: sources are
-// consumed in DESCENDING chunks of 64 cells (loaded to registers first) and every edge goes to a
-// cell index >= its source (speeds are >= 0), so a target never lands on a source that is still
-// unread.  Live cells at any time lie in [wlo, ihi), which must fit in W.
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT>
-__device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, unsigned *hist, double *pen,
-                             int *path_lds) {
+//   list[]  u16  cells of the current layer selected for expansion, highest first
+// ONE cost/hist array serves both the layer being expanded and the layer being built: the listed sources
+// are consumed in DESCENDING rounds of 64*NW cells, each round first loads its sources into registers
+// (barrier), and every edge goes to a cell index >= its source (speeds are >= 0), so a target never lands
+// on a source that is still unread.
+//
+// Exact (cost, predecessor) minimum across waves, per round:
+//   A  every candidate: old = atomic_min(cost[cell], bits(total));  remember bits, old>bits, old==bits
+//   -- barrier --
+//   B  candidates that strictly improved the cell at their time and still hold it (cost[cell]==bits) are the
+//      unique first setter of the final value: hist[cell] = key
+//   -- barrier --
+//   C  candidates that met an equal value and still match the final cost: atomic_min(hist[cell], key);
+//      key has the predecessor index in the high half, so the smaller predecessor wins (st_cy.pyx:388 order)
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX>
+__device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
+                       u16 *list, int *chunk_cnt, u64 ubits, double band, bool hardsoft, PassOut &out) {
     typedef Mem<USE_LDS> M;
     const DevP &p = a.p;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int NW = blockDim.x >> 6;
+    const int per = blockDim.x;
     const int W = a.W, WM = a.W - 1;
-    const int H = p.H;
-    double start_s, v0, a0, s1, delta;
-    int S;
-    if constexpr (GRID) {
-        start_s = a.s_values[0]; s1 = a.s_values[1]; delta = s1 - start_s;      // st_cy.pyx:318,320
-        v0 = a.v0_grid; a0 = a.a0_grid; S = a.S_grid;
-    } else {
-        start_s = a.ego[(size_t)e * 5 + 4]; v0 = a.ego[(size_t)e * 5 + 2]; a0 = a.ego[(size_t)e * 5 + 3];
-        s1 = start_s + p.ds; delta = s1 - start_s; S = a.tab.num_s[e];
-    }
+    const int H = p.H, S = ep.S, e = ep.e;
+    const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
-    const double r_dt = 1.0 / dt, r_dt2 = 1.0 / dt2, r_dt3 = 1.0 / dt3, r_delta = 1.0 / delta;
-    // st_cy.pyx:329-330 virtual history
-    const double est_prev = start_s - v0 * dt;
-    const double est_second = est_prev - dt * (v0 - a0 * dt);
-    const bool s1_plain = (start_s + 1.0 * delta == s1);      // numpy arange: a[1] = start+step, a[i>=2] = start+i*delta
+    const double r_dt = ep.r_dt, r_dt2 = ep.r_dt2, r_dt3 = ep.r_dt3, r_delta = ep.r_delta;
+    const bool s1_plain = ep.s1_plain;
     auto sval = [&](int n) -> double {
         if constexpr (GRID) return a.s_values[n];
         else {
-            double v = start_s + (double)n * delta;
-            if (!s1_plain) { if (n == 1) v = s1; }
+            double v = start_s + (double)n * delta;      // numpy arange: a[i>=2] = start + i*delta
+            if (!s1_plain) { if (n == 1) v = s1; }       //               a[1]    = start + step
             return v;
         }
     };
-    u16 *bp = a.bp + (size_t)slot * H * W;
+    u16 *bp = ep.bp;
 
-    if (lane == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); }
-    M::order();
+    __syncthreads();                       // previous users of the arrays are done
+    if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
+    __syncthreads();
     int wlo = 0, whi = 1;
-    int best_t = 0, best_n = 0;
-    u64 best_bits = 0ull;
+    out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
+    u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
+    int total_nodes = 0;
 
-    for (int t = 0; t < H; ++t) {
+    const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
+    for (int t = 0; t <= last_src_layer; ++t) {
         const bool relax = t < H - 1;
         int ilo = 0, ihi = 0;
         bool first = true;
         u64 my_best = ~0ull;
         int my_best_n = 0x7fffffff;
-        int n_active = 0;
-        // obstructing vehicles of layer t+1 (wave-uniform): kept in SGPRs when KT > 0
+        u64 my_min_tot = ~0ull;
+        u64 thr = ubits;
+        if constexpr (MODE == PASS_BOUND) {
+            const double lim = __longlong_as_double((long long)lmin) + band;
+            const u64 lb = (u64)__double_as_longlong(lim);
+            if (lb < thr) thr = lb;
+        }
+        // obstructing vehicles of layer t+1 (wave-uniform): kept in scalar registers when KT > 0
         int nact = 0;
         double cfront[KT > 0 ? KT : 1], cback[KT > 0 ? KT : 1];
         int cimin[KT > 0 ? KT : 1], cimax[KT > 0 ? KT : 1];
@@ -427,19 +491,22 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
                 cedge = a.tab.edge + row * a.Kmax * 2;
                 cwin = a.tab.win + row * a.Kmax * 2;
                 if constexpr (KT > 0) {
-                    // lane c loads vehicle c, then broadcast to scalars
-                    double f = 0.0, b = 0.0; int i0 = 0, i1 = 0;
-                    if (lane < nact) { f = cedge[lane * 2]; b = cedge[lane * 2 + 1]; i0 = cwin[lane * 2]; i1 = cwin[lane * 2 + 1]; }
+                    double f = 0.0, b = 0.0; int i0 = 0, i1 = 0;     // lane c loads vehicle c, then broadcast
+                    if (lane < KT) { f = cedge[lane * 2]; b = cedge[lane * 2 + 1]; i0 = cwin[lane * 2]; i1 = cwin[lane * 2 + 1]; }
 #pragma unroll
                     for (int c = 0; c < KT; ++c) {
-                        cfront[c] = __shfl(f, c); cback[c] = __shfl(b, c);
-                        cimin[c] = __shfl(i0, c); cimax[c] = __shfl(i1, c);
+                        cfront[c] = __longlong_as_double(((long long)__builtin_amdgcn_readlane(__double2hiint(f), c) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane(__double2loint(f), c));
+                        cback[c] = __longlong_as_double(((long long)__builtin_amdgcn_readlane(__double2hiint(b), c) << 32) |
+                                                        (unsigned)__builtin_amdgcn_readlane(__double2loint(b), c));
+                        cimin[c] = __builtin_amdgcn_readlane(i0, c);
+                        cimax[c] = __builtin_amdgcn_readlane(i1, c);
                     }
                 }
             }
         }
-        auto init_cells = [&](int from, int to) {
-            for (int n = from + lane; n < to; n += 64) {
+        auto init_cells = [&](int from, int to) {            // all threads of the workgroup stride over the range
+            for (int n = from + tid; n < to; n += per) {
                 double pv;
                 if constexpr (GRID) {
                     pv = -1.0;
@@ -455,52 +522,93 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
 #pragma unroll
                         for (int c = 0; c < KT; ++c) {
                             if (c < nact) {
-                                double f = fabs(sn - cfront[c]);
-                                double b = fabs(sn - cback[c]);
-                                d = (f < d) ? f : d; d = (b < d) ? b : d;    // st.py:56-57
+                                d = __builtin_fmin(d, fabs(sn - cfront[c]));  // st.py:56-57 (operands are >= 0, never NaN)
+                                d = __builtin_fmin(d, fabs(sn - cback[c]));
                                 blocked |= (n >= cimin[c]) & (n < cimax[c]); // st.py:64
                             }
                         }
                     } else {
                         for (int c = 0; c < nact; ++c) {
-                            double f = fabs(sn - cedge[c * 2 + 0]);
-                            double b = fabs(sn - cedge[c * 2 + 1]);
-                            d = (f < d) ? f : d; d = (b < d) ? b : d;
+                            d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 0]));
+                            d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 1]));
                             blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
                         }
                     }
+                    if constexpr (MODE == PASS_BOUND) { if (hardsoft && d < p.min_allowed) blocked = true; }
                     pv = blocked ? -1.0 : dev_weighted_penalty(d, p.min_allowed, p.d_w);
                 }
                 M::stf(&pen[n & WM], pv);
                 M::st64(&cost[n & WM], INF_BITS);
             }
-            M::order();
         };
 
-        // sources of layer t, highest cells first
-        for (int top = (whi + 63) & ~63; top > wlo; top -= 64) {      // chunks aligned to multiples of 64 cells
-            const int i = top - 64 + lane;
-            const bool valid = (i >= wlo) & (i < whi);
-            const u64 cb = valid ? M::ld64(&cost[i & WM]) : INF_BITS;
-            const bool act = cb < INF_BITS;
+        // ---- scan: compact the cells of layer t that get expanded (cost <= thr) into list[], highest first.
+        // 64-cell chunks, chunk j = cells [top0-64(j+1), top0-64j), dealt round-robin to the waves.
+        const int top0 = (whi + 63) & ~63;
+        const int nch = (top0 - (wlo & ~63)) >> 6;
+        bool pruned_l = false;
+        for (int jc = wave; jc < nch; jc += NW) {            // count
+            const int i = top0 - 64 * (jc + 1) + lane;
+            const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
+            const bool reached = cb < INF_BITS;
+            const bool act = cb <= thr && reached;
+            pruned_l |= reached && !act;
             const u64 amask = __ballot(act);
-            if (!amask) continue;
-            n_active += __popcll(amask);
+            if (act) { if (cb < my_best || (cb == my_best && i < my_best_n)) { my_best = cb; my_best_n = i; } }
+            if (lane == 0) chunk_cnt[jc] = __popcll(amask);
+        }
+        if (__ballot(pruned_l) && lane == 0) atomicOr(&sh.flags, 1);
+        __syncthreads();
+        if (wave == 0) {                                     // exclusive prefix of the chunk counts
+            int carry = 0;
+            for (int base = 0; base < nch; base += 64) {
+                const int j = base + lane;
+                const int c = (j < nch) ? chunk_cnt[j] : 0;
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                if (j < nch) chunk_cnt[j] = carry + incl - c;
+                carry += __shfl(incl, 63);
+            }
+            if (lane == 0) sh.nlist = carry;
+        }
+        __syncthreads();
+        const int nlist = sh.nlist;
+        for (int jc = wave; jc < nch; jc += NW) {            // write
+            const int i = top0 - 64 * (jc + 1) + lane;
+            const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
+            const bool act = cb <= thr && cb < INF_BITS;
+            const u64 amask = __ballot(act);
+            if (act) {
+                const int above = (lane == 63) ? 0 : __popcll(amask >> (lane + 1));
+                M::st16(&list[chunk_cnt[jc] + above], (u16)i);
+            }
+        }
+        __syncthreads();
+
+        // ---- expand: rounds of 64*NW listed sources, highest cells first
+        for (int r0 = 0; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += per) {
+            const bool act = r0 + tid < nlist;
+            const int i = act ? (int)M::ld16(&list[r0 + tid]) : 0;
+            const int rlast = (r0 + per < nlist ? r0 + per : nlist) - 1;
+            const int a_k = (int)M::ld16(&list[rlast]);          // lowest source of this round (uniform)
+            const int smin = (int)M::ld16(&list[nlist - 1]);     // lowest source of the layer
+            u64 cb = INF_BITS;
+            unsigned h = 0u;
+            if (act) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
             double sv = 0.0, p1 = 0.0, p2 = 0.0;
             const double C = __longlong_as_double((long long)cb);
             int lo = 0, hi = 0;
-            unsigned myh = 0u;        // what a target won by this source stores: i | (p1 index << 16)
+            unsigned key = 0u;        // what a target won by this source stores: i << 16 | p1 index
             if (act) {
-                if (cb < my_best || (cb == my_best && i < my_best_n)) { my_best = cb; my_best_n = i; }
                 sv = sval(i);
-                if (t == 0) { p1 = est_prev; p2 = est_second; myh = 0u; }      // st_cy.pyx:342
+                if (t == 0) { p1 = ep.est_prev; p2 = ep.est_second; key = 0u; }      // st_cy.pyx:342
                 else {
-                    const unsigned h = M::ld32(&hist[i & WM]);
-                    const int pr = (int)(h & 0xFFFFu), pp = (int)(h >> 16);
-                    bp[(size_t)t * W + (i & WM)] = (u16)pr;
+                    const int pr = (int)(h >> 16), pp = (int)(h & 0xFFFFu);
+                    if constexpr (MODE == PASS_EXACT) bp[(size_t)t * W + (i & WM)] = (u16)pr;
                     p1 = sval(pr);
-                    p2 = (t == 1) ? est_prev : sval(pp);
-                    myh = (unsigned)i | ((unsigned)pr << 16);
+                    p2 = (t == 1) ? ep.est_prev : sval(pp);
+                    key = ((unsigned)i << 16) | (unsigned)pr;
                 }
                 if (relax) {
                     // st_cy.pyx:65-75
@@ -524,171 +632,310 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, u64 *cost, uns
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
             }
-            M::order();      // this chunk's cost/hist are in registers: its cells may now be overwritten
+            if (relax) {
+                const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
+                const int fan_w = wave_max_i(hi - lo);
+                if (lane == 0) { sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w; }
+            }
+            __syncthreads();     // B1: the round's sources are in registers: their cells may now be overwritten
             if (!relax) continue;
-            int clo = wave_min_i(hi > lo ? lo : 0x7fffffff), chi = wave_max_i(hi);
-            if (clo >= chi) continue;
-            // the interval of initialised next-layer cells grows in whole 64-cell blocks: clo >= top-64 (a
-            // multiple of 64), so rounding down never touches a source that is still unread
-            clo &= ~63; chi = (chi + 63) & ~63;
+            int clo = 0x7fffffff, chi = 0, fan = 0;
+            for (int w = 0; w < NW; ++w) {
+                const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
+                clo = l_ < clo ? l_ : clo; chi = h_ > chi ? h_ : chi; fan = f_ > fan ? f_ : fan;
+            }
+            if (clo >= chi) { __syncthreads(); continue; }       // (keeps sh.red stable until everyone has read it)
+            // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
+            // below a_k, the lowest source of this round (lower cells may hold sources that are still unread;
+            // cells >= a_k are either in registers or were not selected for expansion)
+            clo &= ~63; if (clo < a_k) clo = a_k;
+            chi = (chi + 63) & ~63;
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
-            if (nhi2 - (wlo & ~63) > W) return 1;                            // live cells exceed the circular window
+            if (nhi2 - smin > W) return 1;                                   // live cells exceed the circular window
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
+            __syncthreads();     // B2: next-layer cells of this round are initialised
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
-            for (int c = 0;; ++c) {
-                const int n = lo + c;
-                if (!__ballot(n < hi)) break;                                // inactive lanes have lo = hi = 0
-                bool tie = false;
-                int sl = 0;
-                if (n < hi) {
-                    sl = n & WM;
-                    const double pn = M::ldf(&pen[sl]);
-                    if (pn >= 0.0) {                                         // st_cy.pyx:383 obstacle skip
-                        const double sn = sval(n);
-                        // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
-                        const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
-                        const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
-                        const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
-                        const double dv = v - p.v_des;
-                        const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn;
-                        const double tot = C + ec;                           // st_cy.pyx:388
-                        const u64 tb = (u64)__double_as_longlong(tot);
-                        const u64 old = M::min64(&cost[sl], tb);
-                        M::order();
-                        const u64 cur = M::ld64(&cost[sl]);
-                        if (cur == tb) {
-                            if (old > tb) M::st32(&hist[sl], myh);           // unique first setter of this value
-                            else tie = true;                                 // equal cost already present
+            for (int cbase = 0; cbase < fan; cbase += FANMAX) {
+                u64 tb[FANMAX];
+                unsigned improved = 0u, tied = 0u;
+                // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
+                constexpr int UB = (FANMAX < 8) ? FANMAX : 8;
+#pragma unroll
+                for (int ub = 0; ub < FANMAX; ub += UB) {
+                    if (__ballot(lo + cbase + ub < hi)) {
+                        double pn[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int n = lo + cbase + ub + u;
+                            pn[u] = -1.0;
+                            if (n < hi) pn[u] = M::ldf(&pen[n & WM]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int n = lo + cbase + ub + u;
+                            tb[ub + u] = ~0ull;
+                            if (n < hi && pn[u] >= 0.0) {                    // st_cy.pyx:383 obstacle skip
+                                const double sn = sval(n);
+                                // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
+                                const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
+                                const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
+                                const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
+                                const double dv = v - p.v_des;
+                                const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn[u];
+                                const double tot = C + ec;                   // st_cy.pyx:388
+                                tb[ub + u] = (u64)__double_as_longlong(tot);
+                                if constexpr (MODE == PASS_BOUND) { if (tb[ub + u] < my_min_tot) my_min_tot = tb[ub + u]; }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            if (tb[ub + u] != ~0ull) {
+                                const u64 old = M::min64(&cost[(lo + cbase + ub + u) & WM], tb[ub + u]);
+                                if (old > tb[ub + u]) improved |= 1u << (ub + u);
+                                else if (old == tb[ub + u]) tied |= 1u << (ub + u);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) tb[ub + u] = ~0ull;
+                    }
+                }
+                __syncthreads();     // B3: every min of this round is in
+                // stage B: the unique first setter of a cell's final value records the predecessor
+#pragma unroll
+                for (int u = 0; u < FANMAX; ++u) {
+                    if ((improved >> u) & 1u) {
+                        const int sl = (lo + cbase + u) & WM;
+                        if (M::ld64(&cost[sl]) == tb[u]) M::st32(&hist[sl], key);
+                    }
+                }
+                __syncthreads();     // B4
+                if constexpr (MODE == PASS_EXACT) {
+                    // stage C: equal total cost -> the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
+#pragma unroll
+                    for (int u = 0; u < FANMAX; ++u) {
+                        if ((tied >> u) & 1u) {
+                            const int sl = (lo + cbase + u) & WM;
+                            if (M::ld64(&cost[sl]) == tb[u]) M::min32(&hist[sl], key);
                         }
                     }
                 }
-                M::order();
-                // equal total cost: the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
-                u64 tm = __ballot(tie);
-                while (tm) {
-                    const int l = __ffsll((long long)tm) - 1;
-                    tm &= tm - 1;
-                    if (lane == l) { unsigned q = M::ld32(&hist[sl]); if ((unsigned)i < (q & 0xFFFFu)) M::st32(&hist[sl], myh); }
-                    M::order();
-                }
             }
         }
-        if (n_active == 0) break;            // layer t is empty: the deepest layer reached is t-1
-        wave_min_key(my_best, my_best_n);
-        best_t = t; best_n = my_best_n; best_bits = my_best;
+
+        // ---- layer summary across the waves
+        total_nodes += nlist;
+        if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
+        if constexpr (MODE == PASS_EXACT) {
+            wave_min_key(my_best, my_best_n);
+            if (lane == 0) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
+        } else {
+            int dummy = 0;
+            wave_min_key(my_min_tot, dummy);
+            if (lane == 0) sh.min_tot[wave] = my_min_tot;
+        }
+        __syncthreads();
+        if constexpr (MODE == PASS_EXACT) {
+            u64 bb = ~0ull; int bn = 0x7fffffff;
+            for (int w = 0; w < NW; ++w) {
+                const u64 b_ = sh.best_bits[w]; const int n_ = sh.best_n[w];
+                if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
+            }
+            out.best_t = t; out.best_n = bn; out.best_bits = bb;
+        } else {
+            u64 mt = ~0ull;
+            for (int w = 0; w < NW; ++w) { const u64 m_ = sh.min_tot[w]; mt = m_ < mt ? m_ : mt; }
+            lmin = mt;
+            if (mt < INF_BITS) { out.best_t = t + 1; out.best_bits = mt; }
+        }
         if (!relax) break;
         if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
+        __syncthreads();                     // sh.best_* / sh.min_tot may be rewritten by the next layer
     }
+    __syncthreads();
+    out.pruned = (sh.flags & 1) != 0;
+    out.nodes = total_nodes;
+    return 0;
+}
 
-    // back-track (st_cy.pyx:391-398)
+// Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
+__device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
+                             double *pen, u16 *list, int *chunk_cnt) {
+    const DevP &p = a.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int W = a.W, WM = a.W - 1;
+    const int H = p.H;
+    Ep ep;
+    if constexpr (GRID) {
+        ep.start_s = a.s_values[0]; ep.s1 = a.s_values[1]; ep.delta = ep.s1 - ep.start_s;      // st_cy.pyx:318,320
+        ep.v0 = a.v0_grid; ep.a0 = a.a0_grid; ep.S = a.S_grid;
+    } else {
+        ep.start_s = a.ego[(size_t)e * 5 + 4]; ep.v0 = a.ego[(size_t)e * 5 + 2]; ep.a0 = a.ego[(size_t)e * 5 + 3];
+        ep.s1 = ep.start_s + p.ds; ep.delta = ep.s1 - ep.start_s; ep.S = a.tab.num_s[e];
+    }
+    ep.e = e;
+    const double dt = p.dt;
+    ep.r_dt = 1.0 / dt; ep.r_dt2 = 1.0 / p.dt2; ep.r_dt3 = 1.0 / p.dt3; ep.r_delta = 1.0 / ep.delta;
+    // st_cy.pyx:329-330 virtual history
+    ep.est_prev = ep.start_s - ep.v0 * dt;
+    ep.est_second = ep.est_prev - dt * (ep.v0 - ep.a0 * dt);
+    ep.s1_plain = (ep.start_s + 1.0 * ep.delta == ep.s1);
+    ep.bp = a.bp + (size_t)slot * H * W;
+    const double start_s = ep.start_s, delta = ep.delta;
+    const int S = ep.S;
+    auto sval = [&](int n) -> double {
+        if constexpr (GRID) return a.s_values[n];
+        else {
+            double v = start_s + (double)n * delta;
+            if (!ep.s1_plain) { if (n == 1) v = ep.s1; }
+            return v;
+        }
+    };
+
+    PassOut out;
+    u64 ubits = INF_BITS;
+    if constexpr (!GRID) {
+        if (a.prune) {
+            // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
+            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, INF_BITS, a.band, true, out);
+            int bn = out.nodes;
+            if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
+            else {
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, INF_BITS, a.band * 20.0, false, out);
+                bn += out.nodes;
+                if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
+            }
+            if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
+        }
+    }
+    for (int attempt = 0;; ++attempt) {
+        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ubits, 0.0, false, out);
+        if (rc != 0) return rc;
+        if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
+        if (out.best_t == H - 1 || !out.pruned) break;
+        // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
+        if (attempt >= 3) ubits = INF_BITS;
+        else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * 1.25);
+        if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);
+    }
+    const int best_t = out.best_t, best_n = out.best_n;
+    const u64 best_bits = out.best_bits;
+    u16 *bp = ep.bp;
+
+    // back-track (st_cy.pyx:391-398); the back-pointers were written by all waves
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
         int n = best_n;
         for (int t = best_t; t > 0; --t) {
-            path_lds[t] = n;
+            sh.path[t] = n;
             n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        path_lds[0] = n;
+        sh.path[0] = n;
     }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0);   // lane 0's LDS writes visible to the wave
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __syncthreads();
 
-    // outputs; path distance probe of st.py:797-800
-    bool crash_l = false;
-    if (lane < H) {
-        const int t = lane;
-        int n = (t <= best_t) ? *(volatile int *)&path_lds[t] : -1;
-        double pd = __builtin_nan("");
-        if (n >= 0) {
-            double s_t = sval(n);
-            int qi = (int)((s_t - start_s) / delta);                          // st.py:798 -> st.py:20-22
-            double d;
-            if constexpr (GRID) {
-                d = a.distances[(size_t)t * S + qi];
-            } else {
-                size_t row = (size_t)e * H + t;
-                int na = a.tab.nact[row];
-                const double *ce = a.tab.edge + row * a.Kmax * 2;
-                const int *cw = a.tab.win + row * a.Kmax * 2;
-                double sq = sval(qi);
-                d = 1e10;
-                bool blocked = false;
-                for (int c = 0; c < na; ++c) {
-                    double f = fabs(sq - ce[c * 2 + 0]);
-                    double b = fabs(sq - ce[c * 2 + 1]);
-                    d = (f < d) ? f : d; d = (b < d) ? b : d;
-                    blocked |= (qi >= cw[c * 2 + 0]) & (qi < cw[c * 2 + 1]);
+    // outputs; path distance probe of st.py:797-800 (first wave)
+    if (tid < 64) {
+        bool crash_l = false;
+        if (lane < H) {
+            const int t = lane;
+            int n = (t <= best_t) ? sh.path[t] : -1;
+            double pd = __builtin_nan("");
+            if (n >= 0) {
+                double s_t = sval(n);
+                int qi = (int)((s_t - start_s) / delta);                          // st.py:798 -> st.py:20-22
+                double d;
+                if constexpr (GRID) {
+                    d = a.distances[(size_t)t * S + qi];
+                } else {
+                    size_t row = (size_t)e * H + t;
+                    int na = a.tab.nact[row];
+                    const double *ce = a.tab.edge + row * a.Kmax * 2;
+                    const int *cw = a.tab.win + row * a.Kmax * 2;
+                    double sq = sval(qi);
+                    d = 1e10;
+                    bool blocked = false;
+                    for (int c = 0; c < na; ++c) {
+                        double f = fabs(sq - ce[c * 2 + 0]);
+                        double b = fabs(sq - ce[c * 2 + 1]);
+                        d = (f < d) ? f : d; d = (b < d) ? b : d;
+                        blocked |= (qi >= cw[c * 2 + 0]) & (qi < cw[c * 2 + 1]);
+                    }
+                    if (blocked) d = 0.0;
                 }
-                if (blocked) d = 0.0;
+                pd = d;
+                crash_l = d < p.crash_dist_thr;
             }
-            pd = d;
-            crash_l = d < p.crash_dist_thr;
+            if constexpr (GRID) {
+                a.s_sequence[t] = (n >= 0) ? sval(n) : 0.0;                       // st_cy.pyx:393-398
+            } else {
+                a.path_idx[(size_t)e * H + t] = n;
+                if (a.path_dist) a.path_dist[(size_t)e * H + t] = pd;
+            }
         }
-        if constexpr (GRID) {
-            a.s_sequence[t] = (n >= 0) ? sval(n) : 0.0;                       // st_cy.pyx:393-398
-        } else {
-            a.path_idx[(size_t)e * H + t] = n;
-            if (a.path_dist) a.path_dist[(size_t)e * H + t] = pd;
-        }
-    }
-    const bool any_crash = __ballot(crash_l) != 0ull;
-    if constexpr (!GRID) {
-        if (lane == 0) {
-            a.best_t[e] = best_t;
-            a.cost[e] = __longlong_as_double((long long)best_bits);
-            if (a.crash) a.crash[e] = (best_t != H - 1 || any_crash) ? 1 : 0;
+        const bool any_crash = __ballot(crash_l) != 0ull;
+        if constexpr (!GRID) {
+            if (lane == 0) {
+                a.best_t[e] = best_t;
+                a.cost[e] = __longlong_as_double((long long)best_bits);
+                if (a.crash) a.crash[e] = (best_t != H - 1 || any_crash) ? 1 : 0;
+            }
         }
     }
     return 0;
 }
 
-#define STMPC_CELL_BYTES 20     // cost 8 + pen 8 + hist 4
+#define STMPC_CELL_BYTES 22     // cost 8 + pen 8 + hist 4 + list 2
+// dynamic LDS of a tier: the cell arrays (LDS tiers only) + one int per 64-cell chunk
+__host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 64 + 8); }
 
-// Persistent kernel: blocks of one wave pull episodes until the tier's queue is drained.
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT>
-__global__ void __launch_bounds__(64) k_solve(SolveArgs a) {
+// Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
+__global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int path_lds[STMPC_MAXH];
-    const int lane = threadIdx.x;
+    __shared__ WgShared sh;
+    const int tid = threadIdx.x;
     const int W = a.W;
     unsigned char *base;
-    if constexpr (USE_LDS) base = smem;
-    else base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES;
+    int *chunk_cnt;
+    if constexpr (USE_LDS) { base = smem; chunk_cnt = (int *)(smem + (size_t)W * STMPC_CELL_BYTES); }
+    else { base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES; chunk_cnt = (int *)smem; }
     u64 *cost = (u64 *)base;
     double *pen = (double *)(cost + W);
     unsigned *hist = (unsigned *)(pen + W);
+    u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
-        int rc = solve_episode<USE_LDS, true, FASTDIV, 0>(a, 0, 0, cost, hist, pen, path_lds);
-        if (rc != 0 && lane == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
+        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt);
+        if (rc != 0 && tid == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
         for (;;) {
-            int e;
-            if (a.tier == 0) {
-                unsigned w = 0;
-                if (lane == 0) w = atomicAdd(&a.counters[0], 1u);
-                w = __builtin_amdgcn_readfirstlane(w);
-                if (w >= (unsigned)a.N) break;
-                e = (int)w;
-            } else {
-                unsigned w = 0, cnt = 0;
-                if (lane == 0) {
-                    w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
-                    cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid == 0) {
+                int e = -1;
+                if (a.tier == 0) {
+                    unsigned w = atomicAdd(&a.counters[0], 1u);
+                    if (w < (unsigned)a.N) e = (int)w;
+                } else {
+                    unsigned w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
+                    unsigned cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w < cnt) e = a.lists[(size_t)a.tier * a.N + w];
                 }
-                w = __builtin_amdgcn_readfirstlane(w);
-                cnt = __builtin_amdgcn_readfirstlane(cnt);
-                if (w >= cnt) break;
-                e = a.lists[(size_t)a.tier * a.N + w];
+                sh.work = e;
             }
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT>(a, e, blockIdx.x, cost, hist, pen, path_lds);
-            if (rc != 0 && lane == 0) {
+            __syncthreads();
+            const int e = sh.work;
+            if (e < 0) break;
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt);
+            if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
                     a.lists[(size_t)(a.tier + 1) * a.N + pos] = e;
@@ -696,7 +943,6 @@ __global__ void __launch_bounds__(64) k_solve(SolveArgs a) {
                     atomicExch(&a.counters[STMPC_CNT_ERR], 1u);   // the last tier's window covers all S cells
                 }
             }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
         }
     }
 }

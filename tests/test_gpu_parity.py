@@ -55,6 +55,23 @@ def test_batch_matches_reference_golden(fname, gpu_ctx, restore_settings):
         assert np.array_equal(seq, g["s_sequence"][i])
 
 
+@pytest.mark.parametrize("prune,band", [("0", "0"), ("1", "0"), ("1", "3"), ("1", "100000")])
+def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
+    """The banded pre-pass + bounded exact pass returns the same bits as the unbounded DP, whatever the band
+    (a tiny band makes the bound loose or absent, a huge one makes the pre-pass the full search)."""
+    from rl_mpc_lanemerging_amd import _capi, st
+    monkeypatch.setenv("STMPC_PRUNE", prune)
+    if band != "0":
+        monkeypatch.setenv("STMPC_BAND", band)
+    ctx = _capi.Context(0)
+    for fname in STATE_FILES:
+        g = load_golden(fname)
+        p, op = settings_from_golden(g)
+        res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
+        _check(res, g, g["t_values"].size)
+    ctx.close()
+
+
 @pytest.mark.parametrize("tiers", ["64", "256,512", "512,2048", "64,128,256"])
 @pytest.mark.parametrize("fastdiv", ["1", "0"])
 def test_window_overflow_falls_back_exactly(tiers, fastdiv, restore_settings, monkeypatch):
