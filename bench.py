@@ -111,8 +111,10 @@ def main():
     achieved_gbs = bytes_per_solve * n / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "stmpc::k_solve<true,false>", "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve,
-                "note": "algorithmic HBM bytes are ~316 B/solve: the path is fp64-VALU/LDS bound, see fp64_valu"}
+                "kernel": "stmpc::k_solve<true,false,...> (LDS lattice DP; one launch per LDS window tier, summed per step)",
+                "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve,
+                "note": "algorithmic HBM bytes are %d B/solve (SURVEY 8d): the path is fp64-VALU/LDS bound, not HBM bound; "
+                        "see fp64_valu for the bound that applies" % bytes_per_solve}
 
     out = {"metric": "MPC solves/sec (H=40,A=21,K=6)" if args.workload == "h40a21" else "MPC solves/sec (reference default H=18,S=3001,K=6)",
            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -75,7 +75,7 @@ typedef struct stmpc_stats {
     int64_t nodes_exact;     /* lattice nodes expanded by the exact passes (all tiers, incl. repeated work) */
     int64_t nodes_bound;     /* lattice nodes expanded by the bounding pre-passes */
     double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
-    double  dp_kernel_ms;    /* device time of the first-tier lattice DP kernel alone */
+    double  dp_kernel_ms;    /* device time of the LDS lattice-DP kernel launches (all LDS tiers) */
 } stmpc_stats;
 
 /* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */
@@ -83,7 +83,7 @@ typedef struct stmpc_profile_totals {
     int64_t launches;        /* stmpc_solve_batch_device calls */
     int64_t episodes;        /* sum of N */
     double  solve_ms;        /* sum of device time, predictor + DP + second tier (HIP events on the launch stream) */
-    double  dp_kernel_ms;    /* sum of device time of the LDS lattice-DP kernel */
+    double  dp_kernel_ms;    /* sum of device time of the LDS lattice-DP kernel launches (all LDS tiers) */
 } stmpc_profile_totals;
 
 typedef struct stmpc_ctx stmpc_ctx;

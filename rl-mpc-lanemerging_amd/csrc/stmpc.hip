@@ -82,7 +82,7 @@ struct stmpc_ctx {
     int max_waves_per_cu = 16;
     int waves_override = 0;       // STMPC_NW: waves per workgroup (episode) for every tier
     bool allow_fastdiv = true;
-    bool prune = true;
+    int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
     int last_nt = 0;
 };
@@ -143,7 +143,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
     if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) c->waves_override = v; }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
-    if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
     *out = c;
     return STMPC_OK;
@@ -279,6 +279,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const double fan_acc = (dp.a_max - dp.a_min) * dp.dt2 / dp.ds, fan_jerk = (dp.j_max - dp.j_min) * dp.dt3 / dp.ds;
     const double fan_bound = (fan_acc < fan_jerk ? fan_acc : fan_jerk) + 2.0;
     const bool small_fan = fan_bound <= 8.0;
+    const bool stage_tab = Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
 
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack
@@ -288,7 +289,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
         int W = c->lds_tier_W[k];
         if (W >= Wg && nt > 0) break;
-        const size_t lds = (size_t)W * STMPC_CELL_BYTES + stmpc_chunk_ints(W) * sizeof(int);
+        const size_t lds = (size_t)W * STMPC_CELL_BYTES + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) + stmpc_tab_bytes(H, stage_tab ? 8 : 0);
         if (lds + 2048 > (size_t)c->lds_per_block) break;
         tierW[nt] = W; tierLds[nt] = true; tierLdsBytes[nt] = lds;
         tierNW[nt] = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
@@ -300,7 +301,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         ++nt;
     }
     tierW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
-    tierLdsBytes[nt] = stmpc_chunk_ints(Wg) * sizeof(int);
+    tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
     tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     for (int k = 0; k < nt; ++k) {
         if (tierGrid[k] > N) tierGrid[k] = N;
@@ -329,7 +330,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.p = dp; a.N = N; a.Kmax = Kalloc;
     a.ego = d_ego; a.tab = tab;
     a.counters = counters; a.lists = c->lists.as<int>();
-    a.prune = c->prune ? 1 : 0;
+    a.prune = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // band of the bounding pre-pass: a quarter of the per-step cost of standing still (112.5 with the
     // reference's weights); any value is safe (the exact pass re-checks), it only trades pre-pass work for tightness
     a.band = c->band_override > 0 ? c->band_override : fmax(1.0, 0.25 * dp.v_w * dp.v_des * dp.v_des);
@@ -351,14 +352,14 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         } while (0)
 #define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 16); } while (0)
         if (tierLds[k]) {
-            if (Kalloc <= 8) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
+            if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
             else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }
         } else {
             if (fastdiv) STMPC_LAUNCH_FM(false, true, 0); else STMPC_LAUNCH_FM(false, false, 0);
         }
 #undef STMPC_LAUNCH_FM
 #undef STMPC_LAUNCH
-        if (k == 0) HIPCHK(hipEventRecord(e2, st));
+        if (k == nt - 2 || nt == 1) HIPCHK(hipEventRecord(e2, st));      // after the last LDS tier
     }
     HIPCHK(hipEventRecord(e3, st));
     HIPCHK(hipGetLastError());
@@ -501,7 +502,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
     a.s_sequence = c->s_misc3.as<double>();
-    hipLaunchKernelGGL((k_solve<false, true, false, 0, 16>), dim3(1), dim3(256), stmpc_chunk_ints(Wg) * sizeof(int), nullptr, a);
+    hipLaunchKernelGGL((k_solve<false, true, false, 0, 16>), dim3(1), dim3(256), ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16, nullptr, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));

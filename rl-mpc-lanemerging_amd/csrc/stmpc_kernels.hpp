@@ -361,6 +361,12 @@ struct Mem {
     static __device__ __forceinline__ void stf(double *p, double v) {
         __hip_atomic_store((u64 *)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, SCOPE);
     }
+    // Workgroup barrier.  LDS tiers: wait only for this wave's LDS traffic (lgkmcnt) -- outstanding global
+    // back-pointer stores need not be acknowledged here (they are read once, after a full fence).
+    static __device__ __forceinline__ void barrier() {
+        if constexpr (USE_LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    }
     // order this wave's own accesses: LDS is in-order per wave (a compiler barrier suffices);
     // the HBM variant drains the vector-memory queue.
     static __device__ __forceinline__ void order() {
@@ -432,7 +438,8 @@ enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 //      key has the predecessor index in the high half, so the smaller predecessor wins (st_cy.pyx:388 order)
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
-                       u16 *list, int *chunk_cnt, u64 ubits, double band, bool hardsoft, PassOut &out) {
+                       u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
+                       u64 ubits, double band, bool hardsoft, PassOut &out) {
     typedef Mem<USE_LDS> M;
     const DevP &p = a.p;
     const int tid = threadIdx.x;
@@ -456,9 +463,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     };
     u16 *bp = ep.bp;
 
-    __syncthreads();                       // previous users of the arrays are done
+    M::barrier();                       // previous users of the arrays are done
     if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
-    __syncthreads();
+    M::barrier();
     int wlo = 0, whi = 1;
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
@@ -487,12 +494,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         if constexpr (!GRID) {
             if (relax) {
                 size_t row = (size_t)e * H + (t + 1);
-                nact = a.tab.nact[row];
-                cedge = a.tab.edge + row * a.Kmax * 2;
-                cwin = a.tab.win + row * a.Kmax * 2;
                 if constexpr (KT > 0) {
-                    double f = 0.0, b = 0.0; int i0 = 0, i1 = 0;     // lane c loads vehicle c, then broadcast
-                    if (lane < KT) { f = cedge[lane * 2]; b = cedge[lane * 2 + 1]; i0 = cwin[lane * 2]; i1 = cwin[lane * 2 + 1]; }
+                    // staged in LDS by solve_episode: lane c picks vehicle c, then broadcast to scalars
+                    nact = ltab_n[t + 1];
+                    double f = 0.0, b = 0.0; int i0 = 0, i1 = 0;
+                    if (lane < KT) {
+                        f = ltab_e[((t + 1) * KT + lane) * 2]; b = ltab_e[((t + 1) * KT + lane) * 2 + 1];
+                        i0 = ltab_w[((t + 1) * KT + lane) * 2]; i1 = ltab_w[((t + 1) * KT + lane) * 2 + 1];
+                    }
 #pragma unroll
                     for (int c = 0; c < KT; ++c) {
                         cfront[c] = __longlong_as_double(((long long)__builtin_amdgcn_readlane(__double2hiint(f), c) << 32) |
@@ -502,6 +511,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         cimin[c] = __builtin_amdgcn_readlane(i0, c);
                         cimax[c] = __builtin_amdgcn_readlane(i1, c);
                     }
+                } else {
+                    nact = a.tab.nact[row];
+                    cedge = a.tab.edge + row * a.Kmax * 2;
+                    cwin = a.tab.win + row * a.Kmax * 2;
                 }
             }
         }
@@ -558,7 +571,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (lane == 0) chunk_cnt[jc] = __popcll(amask);
         }
         if (__ballot(pruned_l) && lane == 0) atomicOr(&sh.flags, 1);
-        __syncthreads();
+        M::barrier();
         if (wave == 0) {                                     // exclusive prefix of the chunk counts
             int carry = 0;
             for (int base = 0; base < nch; base += 64) {
@@ -572,7 +585,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
             if (lane == 0) sh.nlist = carry;
         }
-        __syncthreads();
+        M::barrier();
         const int nlist = sh.nlist;
         for (int jc = wave; jc < nch; jc += NW) {            // write
             const int i = top0 - 64 * (jc + 1) + lane;
@@ -584,7 +597,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 M::st16(&list[chunk_cnt[jc] + above], (u16)i);
             }
         }
-        __syncthreads();
+        M::barrier();
 
         // ---- expand: rounds of 64*NW listed sources, highest cells first
         for (int r0 = 0; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += per) {
@@ -637,14 +650,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 const int fan_w = wave_max_i(hi - lo);
                 if (lane == 0) { sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w; }
             }
-            __syncthreads();     // B1: the round's sources are in registers: their cells may now be overwritten
+            M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
             if (!relax) continue;
             int clo = 0x7fffffff, chi = 0, fan = 0;
             for (int w = 0; w < NW; ++w) {
                 const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
                 clo = l_ < clo ? l_ : clo; chi = h_ > chi ? h_ : chi; fan = f_ > fan ? f_ : fan;
             }
-            if (clo >= chi) { __syncthreads(); continue; }       // (keeps sh.red stable until everyone has read it)
+            if (clo >= chi) { M::barrier(); continue; }       // (keeps sh.red stable until everyone has read it)
             // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
             // below a_k, the lowest source of this round (lower cells may hold sources that are still unread;
             // cells >= a_k are either in registers or were not selected for expansion)
@@ -656,7 +669,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
-            __syncthreads();     // B2: next-layer cells of this round are initialised
+            M::barrier();     // B2: next-layer cells of this round are initialised
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
             for (int cbase = 0; cbase < fan; cbase += FANMAX) {
@@ -704,7 +717,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         for (int u = 0; u < UB; ++u) tb[ub + u] = ~0ull;
                     }
                 }
-                __syncthreads();     // B3: every min of this round is in
+                M::barrier();     // B3: every min of this round is in
                 // stage B: the unique first setter of a cell's final value records the predecessor
 #pragma unroll
                 for (int u = 0; u < FANMAX; ++u) {
@@ -713,7 +726,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         if (M::ld64(&cost[sl]) == tb[u]) M::st32(&hist[sl], key);
                     }
                 }
-                __syncthreads();     // B4
+                M::barrier();     // B4
                 if constexpr (MODE == PASS_EXACT) {
                     // stage C: equal total cost -> the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
 #pragma unroll
@@ -738,7 +751,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             wave_min_key(my_min_tot, dummy);
             if (lane == 0) sh.min_tot[wave] = my_min_tot;
         }
-        __syncthreads();
+        M::barrier();
         if constexpr (MODE == PASS_EXACT) {
             u64 bb = ~0ull; int bn = 0x7fffffff;
             for (int w = 0; w < NW; ++w) {
@@ -754,9 +767,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
         if (!relax) break;
         if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
-        __syncthreads();                     // sh.best_* / sh.min_tot may be rewritten by the next layer
+        M::barrier();                     // sh.best_* / sh.min_tot may be rewritten by the next layer
     }
-    __syncthreads();
+    M::barrier();
     out.pruned = (sh.flags & 1) != 0;
     out.nodes = total_nodes;
     return 0;
@@ -765,7 +778,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
-                             double *pen, u16 *list, int *chunk_cnt) {
+                             double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n) {
     const DevP &p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -798,16 +811,30 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
     };
 
+    if constexpr (!GRID && KT > 0) {
+        // stage the episode's table of obstructing vehicles (k_predict output) in LDS: one coalesced sweep
+        // instead of two dependent global round trips per layer and pass
+        __syncthreads();
+        const size_t rowbase = (size_t)e * H;
+        for (int x = tid; x < H * KT * 2; x += blockDim.x) {
+            const int t_ = x / (KT * 2), r_ = x - t_ * (KT * 2);
+            const bool in = r_ < a.Kmax * 2;
+            ltab_e[x] = in ? a.tab.edge[(rowbase + t_) * a.Kmax * 2 + r_] : 0.0;
+            ltab_w[x] = in ? a.tab.win[(rowbase + t_) * a.Kmax * 2 + r_] : 0;
+        }
+        for (int x = tid; x < H; x += blockDim.x) ltab_n[x] = a.tab.nact[rowbase + x];
+        __syncthreads();
+    }
     PassOut out;
     u64 ubits = INF_BITS;
     if constexpr (!GRID) {
         if (a.prune) {
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
-            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, INF_BITS, a.band, true, out);
+            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             else {
-                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, INF_BITS, a.band * 20.0, false, out);
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * 20.0, false, out);
                 bn += out.nodes;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
@@ -815,7 +842,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
     }
     for (int attempt = 0;; ++attempt) {
-        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ubits, 0.0, false, out);
+        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out);
         if (rc != 0) return rc;
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
         if (out.best_t == H - 1 || !out.pruned) break;
@@ -895,6 +922,8 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
 #define STMPC_CELL_BYTES 22     // cost 8 + pen 8 + hist 4 + list 2
 // dynamic LDS of a tier: the cell arrays (LDS tiers only) + one int per 64-cell chunk
 __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 64 + 8); }
+// LDS bytes of the staged vehicle table: H*KT*(2 doubles + 2 ints) + H ints (8-byte aligned)
+__host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_t)H * KT * 24 + (((size_t)H * 4 + 7) & ~(size_t)7); }
 
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
@@ -905,15 +934,23 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
     const int W = a.W;
     unsigned char *base;
     int *chunk_cnt;
-    if constexpr (USE_LDS) { base = smem; chunk_cnt = (int *)(smem + (size_t)W * STMPC_CELL_BYTES); }
-    else { base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES; chunk_cnt = (int *)smem; }
+    // dynamic LDS: [vehicle table][chunk counters][cell arrays (LDS tiers only)]
+    const int H = a.p.H;
+    double *ltab_e = (double *)smem;
+    int *ltab_w = (int *)(ltab_e + (size_t)H * (KT > 0 ? KT : 0) * 2);
+    int *ltab_n = ltab_w + (size_t)H * (KT > 0 ? KT : 0) * 2;
+    unsigned char *after_tab = smem + stmpc_tab_bytes(H, KT > 0 ? KT : 0);
+    chunk_cnt = (int *)after_tab;
+    unsigned char *cells = after_tab + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15);
+    if constexpr (USE_LDS) base = cells;
+    else base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES;
     u64 *cost = (u64 *)base;
     double *pen = (double *)(cost + W);
     unsigned *hist = (unsigned *)(pen + W);
     u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
-        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt);
+        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
         if (rc != 0 && tid == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
@@ -934,7 +971,7 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
             __syncthreads();
             const int e = sh.work;
             if (e < 0) break;
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt);
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
