@@ -77,14 +77,16 @@ struct stmpc_ctx {
     size_t pool_used = 0;          // events used (multiple of 4)
     double acc_solve_ms = 0, acc_dp_ms = 0;
     int64_t acc_launches = 0, acc_fallback = 0, acc_episodes = 0;
-    int lds_tier_W[STMPC_MAX_TIERS] = {2048, 4096, 0, 0};   // LDS windows (cells), increasing
-    int n_lds_tiers = 2;
+    int lds_tier_W[STMPC_MAX_TIERS] = {2048, 4096, 8192, 0};   // LDS windows (cells), increasing
+    int n_lds_tiers = 3;
+    int pen_cells[STMPC_MAX_TIERS] = {0, 0, 0, 0};   // STMPC_PEN_CELLS="a,b,c": penalty-buffer cells per LDS tier (0 = min(W, 4096))
     int max_waves_per_cu = 16;
     int waves_override = 0;       // STMPC_NW: waves per workgroup (episode) for every tier
     bool allow_fastdiv = true;
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
     int last_nt = 0;
+    bool last_has_hbm = true;
 };
 
 extern "C" {
@@ -141,6 +143,16 @@ int stmpc_create(stmpc_ctx **out, int device) {
         if (n > 0) c->n_lds_tiers = n;
     }
     if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
+    if (const char *w = getenv("STMPC_PEN_CELLS")) {
+        int n = 0; const char *q = w;
+        while (*q && n < STMPC_MAX_TIERS) {
+            int v = atoi(q);
+            if (v >= 128 && v <= 8192 && (v & (v - 1)) == 0) c->pen_cells[n] = v;
+            ++n;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) c->waves_override = v; }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
@@ -283,16 +295,20 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack
-    int tierW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS]; int tierNW[STMPC_MAX_TIERS];
+    int tierW[STMPC_MAX_TIERS]; int tierPW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS]; int tierNW[STMPC_MAX_TIERS];
     size_t tierLdsBytes[STMPC_MAX_TIERS];
     int nt = 0;
     for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
         int W = c->lds_tier_W[k];
-        if (W >= Wg && nt > 0) break;
-        const size_t lds = (size_t)W * STMPC_CELL_BYTES + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) + stmpc_tab_bytes(H, stage_tab ? 8 : 0);
+        if (W > Wg && nt > 0) break;
+        const int nw = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
+        int PW = c->pen_cells[k] > 0 ? c->pen_cells[k] : 4096;         // penalty buffer: the whole window up to 4096 cells
+        if (PW > W) PW = W;
+        const size_t lds = (size_t)W * STMPC_CELL_BYTES + (size_t)PW * 8 + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) +
+                           stmpc_tab_bytes(H, stage_tab ? 8 : 0);
         if (lds + 2048 > (size_t)c->lds_per_block) break;
-        tierW[nt] = W; tierLds[nt] = true; tierLdsBytes[nt] = lds;
-        tierNW[nt] = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
+        tierW[nt] = W; tierPW[nt] = PW; tierLds[nt] = true; tierLdsBytes[nt] = lds;
+        tierNW[nt] = nw;
         int per_cu = (int)((size_t)(c->lds_per_block) / (lds + 1024));
         int by_waves = c->max_waves_per_cu / tierNW[nt];
         if (per_cu > by_waves) per_cu = by_waves;
@@ -300,14 +316,18 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         tierGrid[nt] = c->num_cu * per_cu;
         ++nt;
     }
-    tierW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
-    tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
-    tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
+    // an LDS tier whose window covers every cell cannot overflow: the HBM-scratch tier is only needed beyond that
+    const bool need_hbm_tier = (nt == 0) || tierW[nt - 1] < Wg || tierPW[nt - 1] < tierW[nt - 1];
+    if (need_hbm_tier) {
+        tierW[nt] = Wg; tierPW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
+        tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
+        tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
+    }
     for (int k = 0; k < nt; ++k) {
         if (tierGrid[k] > N) tierGrid[k] = N;
         if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * sizeof(u16)))) return rc;
     }
-    if ((rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * Wg * STMPC_CELL_BYTES))) return rc;
+    if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + (size_t)Wg * 8)))) return rc;
 
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
@@ -338,7 +358,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 
     HIPCHK(hipEventRecord(e1, st));
     for (int k = 0; k < nt; ++k) {
-        a.W = tierW[k]; a.tier = k; a.last_tier = (k == nt - 1);
+        a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
@@ -359,12 +379,12 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         }
 #undef STMPC_LAUNCH_FM
 #undef STMPC_LAUNCH
-        if (k == nt - 2 || nt == 1) HIPCHK(hipEventRecord(e2, st));      // after the last LDS tier
+        if ((need_hbm_tier && k == nt - 2) || (!need_hbm_tier && k == nt - 1) || nt == 1) HIPCHK(hipEventRecord(e2, st));   // after the last LDS tier
     }
     HIPCHK(hipEventRecord(e3, st));
     HIPCHK(hipGetLastError());
     c->stats.episodes = N;
-    c->last_nt = nt;
+    c->last_nt = nt; c->last_has_hbm = need_hbm_tier;
     c->stats_pending = !c->profiling;
     if (c->profiling) { c->acc_launches += 1; c->acc_episodes += N; }
     return STMPC_OK;
@@ -381,7 +401,7 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         HIPCHK(hipEventElapsedTime(&ms_all, c->ev0, c->ev3));
         HIPCHK(hipEventElapsedTime(&ms_dp, c->ev1, c->ev2));
         c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window
-        c->stats.hbm_tier = c->last_nt >= 2 ? cnt[4 * (c->last_nt - 1)] : 0;
+        c->stats.hbm_tier = (c->last_has_hbm && c->last_nt >= 2) ? cnt[4 * (c->last_nt - 1)] : 0;
         c->stats.fast_path = c->stats.episodes - cnt[4];
         c->stats.retries = cnt[STMPC_CNT_RETRY];
         c->stats.nodes_exact = cnt[STMPC_CNT_NODES_EXACT];
@@ -489,7 +509,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     if ((rc = c->s_misc3.ensure((size_t)H * 8))) return rc;
     if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     const int Wg = next_pow2(S + 2 + 128);
-    if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES))) return rc;
+    if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES + (size_t)Wg * 8))) return rc;
     if ((rc = c->bp_tier[STMPC_MAX_TIERS - 1].ensure((size_t)H * Wg * sizeof(u16)))) return rc;
     HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));
@@ -497,7 +517,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     HIPCHK(hipMemset(c->counters.p, 0, 64 * sizeof(unsigned)));
     SolveArgs a;
     memset(&a, 0, sizeof a);
-    a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.last_tier = 1;
+    a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.PW = Wg; a.last_tier = 1;
     a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();

@@ -317,6 +317,7 @@ struct SolveArgs {
     int N;
     int Kmax;
     int W;                 // window cells of this tier (power of two)
+    int PW;                // cells of the circular penalty buffer (power of two, <= W)
     int tier;              // 0: pull episodes 0..N-1 from counters[0]; k>=1: walk list k
     int last_tier;         // overflow here is an internal error
     int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
@@ -448,6 +449,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const int NW = blockDim.x >> 6;
     const int per = blockDim.x;
     const int W = a.W, WM = a.W - 1;
+    const int PW = a.PW, PWM = a.PW - 1;
     const int H = p.H, S = ep.S, e = ep.e;
     const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
@@ -518,41 +520,60 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 }
             }
         }
-        auto init_cells = [&](int from, int to) {            // all threads of the workgroup stride over the range
-            for (int n = from + tid; n < to; n += per) {
-                double pv;
-                if constexpr (GRID) {
-                    pv = -1.0;
-                    if (n < S) {
-                        size_t at = (size_t)(t + 1) * S + n;
-                        if (!a.obstacles[at]) pv = dev_weighted_penalty(a.distances[at], p.min_allowed, p.d_w);
+        // penalty of cell n in layer t+1 (< 0 = blocked)
+        auto cell_penalty = [&](int n) -> double {
+            double pv;
+            if constexpr (GRID) {
+                pv = -1.0;
+                if (n < S) {
+                    size_t at = (size_t)(t + 1) * S + n;
+                    if (!a.obstacles[at]) pv = dev_weighted_penalty(a.distances[at], p.min_allowed, p.d_w);
+                }
+            } else {
+                const double sn = sval(n);
+                double d = 1e10;                                         // st.py:34-35
+                bool blocked = false;
+                if constexpr (KT > 0) {
+#pragma unroll
+                    for (int c = 0; c < KT; ++c) {
+                        if (c < nact) {
+                            d = __builtin_fmin(d, fabs(sn - cfront[c]));  // st.py:56-57 (operands are >= 0, never NaN)
+                            d = __builtin_fmin(d, fabs(sn - cback[c]));
+                            blocked |= (n >= cimin[c]) & (n < cimax[c]); // st.py:64
+                        }
                     }
                 } else {
-                    const double sn = sval(n);
-                    double d = 1e10;                                         // st.py:34-35
-                    bool blocked = false;
-                    if constexpr (KT > 0) {
-#pragma unroll
-                        for (int c = 0; c < KT; ++c) {
-                            if (c < nact) {
-                                d = __builtin_fmin(d, fabs(sn - cfront[c]));  // st.py:56-57 (operands are >= 0, never NaN)
-                                d = __builtin_fmin(d, fabs(sn - cback[c]));
-                                blocked |= (n >= cimin[c]) & (n < cimax[c]); // st.py:64
-                            }
-                        }
-                    } else {
-                        for (int c = 0; c < nact; ++c) {
-                            d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 0]));
-                            d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 1]));
-                            blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
-                        }
+                    for (int c = 0; c < nact; ++c) {
+                        d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 0]));
+                        d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 1]));
+                        blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
                     }
-                    if constexpr (MODE == PASS_BOUND) { if (hardsoft && d < p.min_allowed) blocked = true; }
-                    pv = blocked ? -1.0 : dev_weighted_penalty(d, p.min_allowed, p.d_w);
                 }
-                M::stf(&pen[n & WM], pv);
+                if constexpr (MODE == PASS_BOUND) { if (hardsoft && d < p.min_allowed) blocked = true; }
+                pv = blocked ? -1.0 : dev_weighted_penalty(d, p.min_allowed, p.d_w);
+            }
+            return pv;
+        };
+        // pen[] is a circular buffer of PW cells; [pv_lo, pv_hi) is the range of cells whose entry is current
+        int pv_lo = 0, pv_hi = 0;
+        auto note_written = [&](int from, int to) {
+            if (to - from > PW) { pv_lo = pv_hi = 0; return; }            // the range aliased itself
+            if (pv_hi > pv_lo && from <= pv_hi && to >= pv_lo) {          // touches the current range
+                int lo2 = from < pv_lo ? from : pv_lo, hi2 = to > pv_hi ? to : pv_hi;
+                if (hi2 - lo2 > PW) { if (from < pv_lo) hi2 = lo2 + PW; else lo2 = hi2 - PW; }   // far end evicted
+                pv_lo = lo2; pv_hi = hi2;
+            } else { pv_lo = from; pv_hi = to; }
+        };
+        auto init_cells = [&](int from, int to) {            // new next-layer cells: penalty + "not reached"
+            for (int n = from + tid; n < to; n += per) {
+                M::stf(&pen[n & PWM], cell_penalty(n));
                 M::st64(&cost[n & WM], INF_BITS);
             }
+            note_written(from, to);
+        };
+        auto repen = [&](int from, int to) {                 // penalty entries that were evicted and are needed again
+            for (int n = from + tid; n < to; n += per) M::stf(&pen[n & PWM], cell_penalty(n));
+            note_written(from, to);
         };
 
         // ---- scan: compact the cells of layer t that get expanded (cost <= thr) into list[], highest first.
@@ -600,25 +621,25 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         M::barrier();
 
         // ---- expand: rounds of 64*NW listed sources, highest cells first
-        for (int r0 = 0; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += per) {
-            const bool act = r0 + tid < nlist;
-            const int i = act ? (int)M::ld16(&list[r0 + tid]) : 0;
-            const int rlast = (r0 + per < nlist ? r0 + per : nlist) - 1;
-            const int a_k = (int)M::ld16(&list[rlast]);          // lowest source of this round (uniform)
+        for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
+            rstep = per;
+            const bool inlist = r0 + tid < nlist;
+            const int i = inlist ? (int)M::ld16(&list[r0 + tid]) : 0;
             const int smin = (int)M::ld16(&list[nlist - 1]);     // lowest source of the layer
             u64 cb = INF_BITS;
             unsigned h = 0u;
-            if (act) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
+            if (inlist) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
             double sv = 0.0, p1 = 0.0, p2 = 0.0;
             const double C = __longlong_as_double((long long)cb);
             int lo = 0, hi = 0;
             unsigned key = 0u;        // what a target won by this source stores: i << 16 | p1 index
-            if (act) {
+            int pr = 0;
+            if (inlist) {
                 sv = sval(i);
                 if (t == 0) { p1 = ep.est_prev; p2 = ep.est_second; key = 0u; }      // st_cy.pyx:342
                 else {
-                    const int pr = (int)(h >> 16), pp = (int)(h & 0xFFFFu);
-                    if constexpr (MODE == PASS_EXACT) bp[(size_t)t * W + (i & WM)] = (u16)pr;
+                    pr = (int)(h >> 16);
+                    const int pp = (int)(h & 0xFFFFu);
                     p1 = sval(pr);
                     p2 = (t == 1) ? ep.est_prev : sval(pp);
                     key = ((unsigned)i << 16) | (unsigned)pr;
@@ -651,13 +672,26 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (lane == 0) { sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w; }
             }
             M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
-            if (!relax) continue;
-            int clo = 0x7fffffff, chi = 0, fan = 0;
-            for (int w = 0; w < NW; ++w) {
-                const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
-                clo = l_ < clo ? l_ : clo; chi = h_ > chi ? h_ : chi; fan = f_ > fan ? f_ : fan;
+            // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer.
+            int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0;
+            if (relax) {
+                kw = 0;
+                for (int w = 0; w < NW; ++w) {
+                    const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
+                    const int l2 = l_ < clo ? l_ : clo, h2 = h_ > chi ? h_ : chi;
+                    if (w > 0 && h2 > l2 && (((h2 + 63) & ~63) - (l2 & ~63)) > PW) break;
+                    clo = l2; chi = h2; fan = f_ > fan ? f_ : fan; kw = w + 1;
+                }
+                rstep = 64 * kw;
             }
+            const bool act = inlist && wave < kw;
+            if constexpr (MODE == PASS_EXACT) { if (act && t > 0) bp[(size_t)t * W + (i & WM)] = (u16)pr; }
+            if (!act) { lo = 0; hi = 0; }
+            if (!relax) continue;
+            const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
+            const int a_k = (int)M::ld16(&list[rlast]);          // lowest source of this round (uniform)
             if (clo >= chi) { M::barrier(); continue; }       // (keeps sh.red stable until everyone has read it)
+            const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
             // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
             // below a_k, the lowest source of this round (lower cells may hold sources that are still unread;
             // cells >= a_k are either in registers or were not selected for expansion)
@@ -666,9 +700,16 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
             if (nhi2 - smin > W) return 1;                                   // live cells exceed the circular window
+            if (chi - clo > PW) return 1;                                    // 64 sources' targets exceed the penalty buffer
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
+            // every cell this round can touch must have a current penalty entry
+            if (!(pv_hi > pv_lo) || need_hi <= pv_lo || need_lo >= pv_hi) repen(need_lo, need_hi);
+            else {
+                if (need_lo < pv_lo) repen(need_lo, pv_lo);
+                if (need_hi > pv_hi) repen(pv_hi, need_hi);
+            }
             M::barrier();     // B2: next-layer cells of this round are initialised
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
@@ -685,7 +726,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         for (int u = 0; u < UB; ++u) {
                             const int n = lo + cbase + ub + u;
                             pn[u] = -1.0;
-                            if (n < hi) pn[u] = M::ldf(&pen[n & WM]);
+                            if (n < hi) pn[u] = M::ldf(&pen[n & PWM]);
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -919,7 +960,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     return 0;
 }
 
-#define STMPC_CELL_BYTES 22     // cost 8 + pen 8 + hist 4 + list 2
+#define STMPC_CELL_BYTES 14     // cost 8 + hist 4 + list 2 per window cell; plus 8 B per penalty-buffer cell
 // dynamic LDS of a tier: the cell arrays (LDS tiers only) + one int per 64-cell chunk
 __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 64 + 8); }
 // LDS bytes of the staged vehicle table: H*KT*(2 doubles + 2 ints) + H ints (8-byte aligned)
@@ -943,10 +984,10 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
     chunk_cnt = (int *)after_tab;
     unsigned char *cells = after_tab + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15);
     if constexpr (USE_LDS) base = cells;
-    else base = a.gscratch + (size_t)blockIdx.x * (size_t)W * STMPC_CELL_BYTES;
+    else base = a.gscratch + (size_t)blockIdx.x * ((size_t)W * STMPC_CELL_BYTES + (size_t)a.PW * 8);
     u64 *cost = (u64 *)base;
     double *pen = (double *)(cost + W);
-    unsigned *hist = (unsigned *)(pen + W);
+    unsigned *hist = (unsigned *)(pen + a.PW);
     u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
