@@ -291,7 +291,8 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const double fan_acc = (dp.a_max - dp.a_min) * dp.dt2 / dp.ds, fan_jerk = (dp.j_max - dp.j_min) * dp.dt3 / dp.ds;
     const double fan_bound = (fan_acc < fan_jerk ? fan_acc : fan_jerk) + 2.0;
     const bool small_fan = fan_bound <= 8.0;
-    const bool stage_tab = Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
+    // the scalar-register vehicle table costs ~48 SGPRs/VGPRs: only with the small-fan kernel (the wide one would spill)
+    const bool stage_tab = small_fan && Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
 
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack

@@ -121,6 +121,27 @@ def test_h40a21_matches_oracle_seeded(gpu_ctx, restore_settings):
     _check(res, ref, 40)
 
 
+@pytest.mark.parametrize("over,k,kmax", [
+    (dict(MAX_POSITIVE_ACCELERATION=5.2, MINIMUM_NEGATIVE_JERK=-35.0, MAXIMUM_POSITIVE_JERK=35.0), 6, 8),     # fan-out 21, H=18
+    (dict(FUTURE_T=2.0, T_DISCRETIZATION=0.5, S_DISCRETIZATION=0.1, FUTURE_S=60.0), 12, 16),                 # H=5, S=601, K>8
+    (dict(S_DISCRETIZATION=0.025, FUTURE_S=100.0, FUTURE_T=3.0), 3, 4),                                      # S=4001, fan-out ~11
+    (dict(MAX_SPEED=12, DESIRED_SPEED=10.0, V_WEIGHT=0.0, A_WEIGHT=0.0, J_WEIGHT=0.0), 6, 8),                # only the gap term: many ties
+])
+def test_other_parameter_sets_match_oracle(over, k, kmax, gpu_ctx, restore_settings):
+    """Kernel variants selected by the parameters (wide/narrow fan-out, staged/unstaged vehicle table, K > 8)."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(over)
+    p = _capi.Params.from_settings(pkg.Settings)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    ego, kc, ox, ov = synth.generate_states(384, k=k, kmax=kmax, seed=77, vary_k=True, dt=p.dt)
+    res = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="heap", nthreads=8)
+    _check(res, ref, _capi.num_t(p))
+
+
 def test_raw_grid_entry_matches_st_cy(gpu_ctx):
     from rl_mpc_lanemerging_amd import st
     g = load_golden("golden_rawgrid.npz")
