@@ -100,7 +100,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    stats = ctx.stats() if False else None
+
+    step()                      # one untimed step outside the profiling window to read the tier statistics
+    torch.cuda.synchronize()
+    tier_stats = ctx.stats()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world * args.steps / elapsed
@@ -125,7 +128,10 @@ def main():
                                   "batched synthetic merge states N=%d/GPU, reference default lattice H=%d, S=%d, K=%d, fp64" % (n, H, S_nom, K),
                       "episodes_per_gpu": n, "H": H, "S": S_nom, "K": K,
                       "collective": "all_gather(action,cost) 16 B/episode" if world > 1 else "none"},
-           "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1)}
+           "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
+           "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
+                     "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]),
+                     "nodes_expanded_per_solve": (tier_stats["nodes_exact"] + tier_stats["nodes_bound"]) / n}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import st_oracle as orc

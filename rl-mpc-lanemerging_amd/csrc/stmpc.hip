@@ -153,7 +153,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
             if (*q == ',') ++q;
         }
     }
-    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) c->waves_override = v; }
+    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v >= 1 && v <= 8) c->waves_override = v; }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
