@@ -65,7 +65,7 @@ struct stmpc_ctx {
     int num_cu = 256;
     int lds_per_block = 65536;
     // scratch
-    DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, gscratch, bp_tier[STMPC_MAX_TIERS];
+    DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -164,7 +164,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->bp_tier[0],
+    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3};
     for (DevBuf *b : all) b->release();
@@ -251,9 +251,9 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, hipStream_t st) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound);
 }
 
 }  // namespace
@@ -286,6 +286,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
     if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     if ((rc = c->lists.ensure((size_t)STMPC_MAX_TIERS * N * sizeof(int)))) return rc;
+    if ((rc = c->ubound.ensure((size_t)N * sizeof(u64)))) return rc;
 
     // widest fan-out the dynamics allow (st_cy.pyx:65-93): acceleration- or jerk-limited window, +2 for rounding
     const double fan_acc = (dp.a_max - dp.a_min) * dp.dt2 / dp.ds, fan_jerk = (dp.j_max - dp.j_min) * dp.dt3 / dp.ds;
@@ -342,15 +343,15 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         c->pool_used += 4;
     }
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
     a.p = dp; a.N = N; a.Kmax = Kalloc;
     a.ego = d_ego; a.tab = tab;
-    a.counters = counters; a.lists = c->lists.as<int>();
+    a.counters = counters; a.lists = c->lists.as<int>(); a.ubound = c->ubound.as<u64>();
     a.prune = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // band of the bounding pre-pass: a quarter of the per-step cost of standing still (112.5 with the
     // reference's weights); any value is safe (the exact pass re-checks), it only trades pre-pass work for tightness
@@ -569,9 +570,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());

@@ -194,10 +194,11 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 const int *__restrict__ k_count,
                                                 const double *__restrict__ other_x,
                                                 const double *__restrict__ other_v, CarTab tab,
-                                                unsigned *counters /* [64], zeroed here */) {
+                                                unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 64) counters[e] = 0u;
     if (e >= N) return;
+    if (ubound) ubound[e] = 0ull;
     DState<KMAX> s;
     s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
     double start_s = ego[e * 5 + 4];
@@ -336,6 +337,7 @@ struct SolveArgs {
     unsigned char *gscratch;   // HBM-storage variant: [blocks][20*W] bytes
     unsigned *counters;    // [0] tier-0 work counter; [4k] list-k length, [4k+1] list-k work counter; [63] error flag
     int *lists;            // [STMPC_MAX_TIERS][N] episode ids queued for tier k
+    u64 *ubound;           // [N] cost bound an episode had when it overflowed a tier (handed to the next tier)
     // outputs
     int *path_idx;         // [N][H]
     int *best_t;           // [N]
@@ -717,7 +719,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
-                constexpr int UB = (FANMAX < 8) ? FANMAX : 8;
+                constexpr int UB = (FANMAX % 8 == 0) ? 8 : (FANMAX % 11 == 0 ? 11 : FANMAX);
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
                     if (__ballot(lo + cbase + ub < hi)) {
@@ -868,8 +870,13 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     }
     PassOut out;
     u64 ubits = INF_BITS;
+    bool have_bound = false;
     if constexpr (!GRID) {
-        if (a.prune) {
+        if (a.prune && a.tier > 0) {          // the previous tier already bounded this episode before it overflowed
+            const u64 ub = a.ubound[e];
+            if (ub != 0ull) { ubits = ub; have_bound = true; }
+        }
+        if (a.prune && !have_bound) {
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
             int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
@@ -884,7 +891,10 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     }
     for (int attempt = 0;; ++attempt) {
         int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out);
-        if (rc != 0) return rc;
+        if (rc != 0) {
+            if constexpr (!GRID) { if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits; }   // 0 is reserved for "unknown"
+            return rc;
+        }
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
         if (out.best_t == H - 1 || !out.pruned) break;
         // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
