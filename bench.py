@@ -48,9 +48,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("STMPC_BENCH_FORCE_DIST") == "1"     # the flag exercises the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
@@ -71,18 +75,18 @@ def main():
     d_cost = torch.empty(n, dtype=torch.float64, device=dev)
     d_pd = torch.empty((n, H), dtype=torch.float64, device=dev)
     d_crash = torch.empty(n, dtype=torch.int32, device=dev)
-    gathered = torch.empty((n * world, 2), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((n * world, 2), dtype=torch.float64, device=dev) if use_dist else None
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         ctx.solve_batch_device(params, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
                                d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_pd.data_ptr(),
                                d_crash.data_ptr(), stream)
-        if world > 1:
-            sharding.gather_actions(sharding.pack_actions(d_path, d_cost), world, gathered)
+        if use_dist:
+            sharding.gather_actions(sharding.pack_actions(d_path, d_cost), world, gathered, force=True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -96,10 +100,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must hold every rank's (action, cost): check this rank's own rows of the gathered buffer
+        own = gathered[rank * n:(rank + 1) * n]
+        assert torch.equal(own[:, 0].to(torch.int32), d_path[:, 1]) and torch.equal(own[:, 1], d_cost), "gather mismatch"
 
     step()                      # one untimed step outside the profiling window to read the tier statistics
     torch.cuda.synchronize()
@@ -127,7 +134,7 @@ def main():
                                   % (n, H, S_nom, K) if args.workload == "h40a21" else
                                   "batched synthetic merge states N=%d/GPU, reference default lattice H=%d, S=%d, K=%d, fp64" % (n, H, S_nom, K),
                       "episodes_per_gpu": n, "H": H, "S": S_nom, "K": K,
-                      "collective": "all_gather(action,cost) 16 B/episode" if world > 1 else "none"},
+                      "collective": "all_gather(action,cost) 16 B/episode" if use_dist else "none"},
            "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
            "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
                      "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]),
@@ -162,10 +169,17 @@ def main():
                             "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                             "frac": (flops_per_solve * n / (dp_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if dp_ms > 0 else 0.0,
                             "edges_per_solve": ref["edges"] / m, "nodes_per_solve": ref["nodes"] / m}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio: flush it first so that the JSON line is the last line of stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

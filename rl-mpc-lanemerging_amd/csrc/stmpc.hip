@@ -85,6 +85,7 @@ struct stmpc_ctx {
     bool allow_fastdiv = true;
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
+    double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
     int last_nt = 0;
     bool last_has_hbm = true;
 };
@@ -157,6 +158,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
+    if (const char *w = getenv("STMPC_SKIP_FRAC")) c->skip_frac = atof(w);
     *out = c;
     return STMPC_OK;
 }
@@ -361,6 +363,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     HIPCHK(hipEventRecord(e1, st));
     for (int k = 0; k < nt; ++k) {
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
+        a.skip_span = (int)(c->skip_frac * tierW[k]);
         a.bp = c->bp_tier[k].as<u16>();
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];

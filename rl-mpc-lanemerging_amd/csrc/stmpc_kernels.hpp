@@ -323,6 +323,7 @@ struct SolveArgs {
     int last_tier;         // overflow here is an internal error
     int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
     double band;           // cost band of the pre-pass
+    int skip_span;         // forward an episode to the next tier without an exact pass when its pre-pass already spanned this many cells (0 = never)
     // table mode inputs
     const double *ego;     // [N][5]
     CarTab tab;
@@ -392,6 +393,7 @@ struct PassOut {
     u64 best_bits;
     bool pruned;       // some reached node was not expanded (bound / band) or some cell was withheld
     int nodes;         // expanded nodes
+    int maxspan;       // widest live span (cells) the pass needed
 };
 
 // Workgroup-shared scratch of one episode (LDS in every variant).
@@ -474,6 +476,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
     int total_nodes = 0;
+    int maxspan = 0;
 
     const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
     for (int t = 0; t <= last_src_layer; ++t) {
@@ -701,6 +704,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             chi = (chi + 63) & ~63;
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
+            if (nhi2 - smin > maxspan) maxspan = nhi2 - smin;
             if (nhi2 - smin > W) return 1;                                   // live cells exceed the circular window
             if (chi - clo > PW) return 1;                                    // 64 sources' targets exceed the penalty buffer
             if (clo < ilo) init_cells(clo, ilo);
@@ -815,6 +819,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     M::barrier();
     out.pruned = (sh.flags & 1) != 0;
     out.nodes = total_nodes;
+    out.maxspan = maxspan;
     return 0;
 }
 
@@ -880,13 +885,20 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
             int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
+            int bspan = out.maxspan;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             else {
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * 20.0, false, out);
                 bn += out.nodes;
+                bspan = out.maxspan;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
+            // the exact pass explores a superset of the pre-pass: if that one was already wide, do not start here
+            if (!a.last_tier && a.skip_span > 0 && (rc != 0 || bspan > a.skip_span)) {
+                if (tid == 0) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
+                return 1;
+            }
         }
     }
     for (int attempt = 0;; ++attempt) {

@@ -24,11 +24,12 @@ def pack_actions(path_idx, cost):
     return buf
 
 
-def gather_actions(local_buf, world_size, out=None):
-    """All-gather the fused per-episode (action, cost) rows of every rank (equal shard sizes)."""
+def gather_actions(local_buf, world_size, out=None, force=False):
+    """All-gather the fused per-episode (action, cost) rows of every rank (equal shard sizes).
+    ``force`` issues the collective even for a single rank (used to exercise the RCCL path on one GPU)."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force:
         return local_buf
     if out is None:
         out = torch.empty((local_buf.shape[0] * world_size, local_buf.shape[1]), dtype=local_buf.dtype,
