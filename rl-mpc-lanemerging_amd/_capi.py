@@ -65,7 +65,8 @@ EXPORTS = (
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # STMPC_LIB selects another build of the same ABI (A/B measurements of kernel variants)
+    return os.environ.get("STMPC_LIB") or _build.LIB_PATH
 
 
 def load():

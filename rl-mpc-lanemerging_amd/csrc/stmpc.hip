@@ -86,6 +86,7 @@ struct stmpc_ctx {
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
     double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
+    bool allow_stage_tab = true;   // STMPC_STAGE_TAB=0: read the vehicle table from HBM/L2 instead of staging it in LDS
     int last_nt = 0;
     bool last_has_hbm = true;
 };
@@ -154,11 +155,12 @@ int stmpc_create(stmpc_ctx **out, int device) {
             if (*q == ',') ++q;
         }
     }
-    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v >= 1 && v <= 8) c->waves_override = v; }
+    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v >= 1 && v <= STMPC_MAXWAVES) c->waves_override = v; }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
     if (const char *w = getenv("STMPC_SKIP_FRAC")) c->skip_frac = atof(w);
+    if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     *out = c;
     return STMPC_OK;
 }
@@ -295,7 +297,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const double fan_bound = (fan_acc < fan_jerk ? fan_acc : fan_jerk) + 2.0;
     const bool small_fan = fan_bound <= 8.0;
     // the scalar-register vehicle table costs ~48 SGPRs/VGPRs: only with the small-fan kernel (the wide one would spill)
-    const bool stage_tab = small_fan && Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
+    const bool stage_tab = c->allow_stage_tab && small_fan && Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
 
     // tiers: LDS windows in increasing size, then one HBM-scratch tier whose window covers every cell
     const int Wg = next_pow2(S_nom + 2 + 128);   // covers every cell plus the 64-cell alignment slack
@@ -308,7 +310,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         const int nw = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
         int PW = c->pen_cells[k] > 0 ? c->pen_cells[k] : 4096;         // penalty buffer: the whole window up to 4096 cells
         if (PW > W) PW = W;
-        const size_t lds = (size_t)W * STMPC_CELL_BYTES + (size_t)PW * 8 + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) +
+        const size_t lds = (size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)PW * 8 + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) +
                            stmpc_tab_bytes(H, stage_tab ? 8 : 0);
         if (lds + 2048 > (size_t)c->lds_per_block) break;
         tierW[nt] = W; tierPW[nt] = PW; tierLds[nt] = true; tierLdsBytes[nt] = lds;
@@ -331,7 +333,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         if (tierGrid[k] > N) tierGrid[k] = N;
         if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * sizeof(u16)))) return rc;
     }
-    if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + (size_t)Wg * 8)))) return rc;
+    if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8)))) return rc;
 
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
@@ -514,7 +516,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     if ((rc = c->s_misc3.ensure((size_t)H * 8))) return rc;
     if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
     const int Wg = next_pow2(S + 2 + 128);
-    if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES + (size_t)Wg * 8))) return rc;
+    if ((rc = c->gscratch.ensure((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8))) return rc;
     if ((rc = c->bp_tier[STMPC_MAX_TIERS - 1].ensure((size_t)H * Wg * sizeof(u16)))) return rc;
     HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));

@@ -397,12 +397,13 @@ struct PassOut {
 };
 
 // Workgroup-shared scratch of one episode (LDS in every variant).
-#define STMPC_MAXWAVES 16
+#define STMPC_MAXWAVES 8
 struct WgShared {
     int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
     u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
     int best_n[STMPC_MAXWAVES];
     u64 min_tot[STMPC_MAXWAVES];          // per-wave cheapest relaxed candidate (PASS_BOUND)
+    int cnt[STMPC_MAXWAVES];              // per-wave number of selected cells of the layer
     int flags;                            // bit 0: a reached node was not expanded
     int nlist;
     int work;                             // episode id broadcast / -1 = queue drained
@@ -581,56 +582,71 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             note_written(from, to);
         };
 
-        // ---- scan: compact the cells of layer t that get expanded (cost <= thr) into list[], highest first.
-        // 64-cell chunks, chunk j = cells [top0-64(j+1), top0-64j), dealt round-robin to the waves.
+        // ---- scan: compact the cells of layer t that get expanded (cost <= thr), highest first.
+        // 64-cell chunks, chunk j = cells [top0-64(j+1), top0-64j); wave w owns the contiguous chunks
+        // [w*cpw, (w+1)*cpw) and writes its cells into its own segment of list[] (capacity cpw*64), so one pass
+        // and one barrier suffice; a global list index is mapped to (segment, offset) with the segment counts.
         const int top0 = (whi + 63) & ~63;
         const int nch = (top0 - (wlo & ~63)) >> 6;
-        bool pruned_l = false;
-        for (int jc = wave; jc < nch; jc += NW) {            // count
-            const int i = top0 - 64 * (jc + 1) + lane;
-            const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
-            const bool reached = cb < INF_BITS;
-            const bool act = cb <= thr && reached;
-            pruned_l |= reached && !act;
-            const u64 amask = __ballot(act);
-            if (act) { if (cb < my_best || (cb == my_best && i < my_best_n)) { my_best = cb; my_best_n = i; } }
-            if (lane == 0) chunk_cnt[jc] = __popcll(amask);
+        const int cpw = (nch + NW - 1) / NW;
+        {
+            bool pruned_l = false;
+            int wn = 0;
+            const int jend = (wave + 1) * cpw < nch ? (wave + 1) * cpw : nch;
+            for (int jc = wave * cpw; jc < jend; ++jc) {
+                const int i = top0 - 64 * (jc + 1) + lane;
+                const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
+                const bool reached = cb < INF_BITS;
+                const bool act = cb <= thr && reached;
+                pruned_l |= reached && !act;
+                const u64 amask = __ballot(act);
+                if (act) {
+                    if (cb < my_best || (cb == my_best && i < my_best_n)) { my_best = cb; my_best_n = i; }
+                    const int above = (lane == 63) ? 0 : __popcll(amask >> (lane + 1));
+                    M::st16(&list[wave * cpw * 64 + wn + above], (u16)i);
+                }
+                wn += __popcll(amask);
+            }
+            if (__ballot(pruned_l) && lane == 0) atomicOr(&sh.flags, 1);
+            if constexpr (MODE == PASS_EXACT) wave_min_key(my_best, my_best_n);
+            if (lane == 0) {
+                sh.cnt[wave] = wn;
+                if constexpr (MODE == PASS_EXACT) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
+            }
         }
-        if (__ballot(pruned_l) && lane == 0) atomicOr(&sh.flags, 1);
-        M::barrier();
-        if (wave == 0) {                                     // exclusive prefix of the chunk counts
-            int carry = 0;
-            for (int base = 0; base < nch; base += 64) {
-                const int j = base + lane;
-                const int c = (j < nch) ? chunk_cnt[j] : 0;
-                int incl = c;
+        M::barrier();        // S1
+        int segbase[STMPC_MAXWAVES + 1];
+        segbase[0] = 0;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                if (j < nch) chunk_cnt[j] = carry + incl - c;
-                carry += __shfl(incl, 63);
+        for (int w = 0; w < STMPC_MAXWAVES; ++w)      // wave-uniform: keep the boundaries in scalar registers
+            segbase[w + 1] = segbase[w] + __builtin_amdgcn_readfirstlane(w < NW ? sh.cnt[w] : 0);
+        const int nlist = segbase[STMPC_MAXWAVES];
+        auto list_at = [&](int g) -> int {                   // g-th selected cell of the layer, descending
+            int w = 0;
+#pragma unroll
+            for (int k = 1; k < STMPC_MAXWAVES; ++k) w += (g >= segbase[k]) ? 1 : 0;
+            int basew = segbase[0];
+#pragma unroll
+            for (int k = 1; k < STMPC_MAXWAVES; ++k) basew = (w == k) ? segbase[k] : basew;
+            return (int)M::ld16(&list[w * cpw * 64 + (g - basew)]);
+        };
+        total_nodes += nlist;
+        if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
+        if constexpr (MODE == PASS_EXACT) {
+            u64 bb = ~0ull; int bn = 0x7fffffff;
+            for (int w = 0; w < NW; ++w) {
+                const u64 b_ = sh.best_bits[w]; const int n_ = sh.best_n[w];
+                if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
             }
-            if (lane == 0) sh.nlist = carry;
+            out.best_t = t; out.best_n = bn; out.best_bits = bb;
         }
-        M::barrier();
-        const int nlist = sh.nlist;
-        for (int jc = wave; jc < nch; jc += NW) {            // write
-            const int i = top0 - 64 * (jc + 1) + lane;
-            const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
-            const bool act = cb <= thr && cb < INF_BITS;
-            const u64 amask = __ballot(act);
-            if (act) {
-                const int above = (lane == 63) ? 0 : __popcll(amask >> (lane + 1));
-                M::st16(&list[chunk_cnt[jc] + above], (u16)i);
-            }
-        }
-        M::barrier();
 
         // ---- expand: rounds of 64*NW listed sources, highest cells first
         for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
             rstep = per;
             const bool inlist = r0 + tid < nlist;
-            const int i = inlist ? (int)M::ld16(&list[r0 + tid]) : 0;
-            const int smin = (int)M::ld16(&list[nlist - 1]);     // lowest source of the layer
+            const int i = inlist ? list_at(r0 + tid) : 0;
+            const int smin = list_at(nlist - 1);                 // lowest source of the layer
             u64 cb = INF_BITS;
             unsigned h = 0u;
             if (inlist) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
@@ -694,7 +710,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (!act) { lo = 0; hi = 0; }
             if (!relax) continue;
             const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
-            const int a_k = (int)M::ld16(&list[rlast]);          // lowest source of this round (uniform)
+            const int a_k = list_at(rlast);                      // lowest source of this round (uniform)
             if (clo >= chi) { M::barrier(); continue; }       // (keeps sh.red stable until everyone has read it)
             const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
             // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
@@ -787,26 +803,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
         }
 
-        // ---- layer summary across the waves
-        total_nodes += nlist;
-        if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
-        if constexpr (MODE == PASS_EXACT) {
-            wave_min_key(my_best, my_best_n);
-            if (lane == 0) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
-        } else {
+        // ---- end of layer.  PASS_EXACT needs no barrier here: the next scan only reads cost[] (final since the
+        // last round's B3) and its own S1 orders everything else.  PASS_BOUND publishes the cheapest candidate.
+        if constexpr (MODE == PASS_BOUND) {
             int dummy = 0;
             wave_min_key(my_min_tot, dummy);
             if (lane == 0) sh.min_tot[wave] = my_min_tot;
-        }
-        M::barrier();
-        if constexpr (MODE == PASS_EXACT) {
-            u64 bb = ~0ull; int bn = 0x7fffffff;
-            for (int w = 0; w < NW; ++w) {
-                const u64 b_ = sh.best_bits[w]; const int n_ = sh.best_n[w];
-                if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
-            }
-            out.best_t = t; out.best_n = bn; out.best_bits = bb;
-        } else {
+            M::barrier();    // S2
             u64 mt = ~0ull;
             for (int w = 0; w < NW; ++w) { const u64 m_ = sh.min_tot[w]; mt = m_ < mt ? m_ : mt; }
             lmin = mt;
@@ -814,7 +817,6 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
         if (!relax) break;
         if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
-        M::barrier();                     // sh.best_* / sh.min_tot may be rewritten by the next layer
     }
     M::barrier();
     out.pruned = (sh.flags & 1) != 0;
@@ -983,6 +985,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
 }
 
 #define STMPC_CELL_BYTES 14     // cost 8 + hist 4 + list 2 per window cell; plus 8 B per penalty-buffer cell
+#define STMPC_LIST_SLACK (64 * (STMPC_MAXWAVES + 1) * 2)   // bytes: per-wave list segments are rounded up to whole chunks
 // dynamic LDS of a tier: the cell arrays (LDS tiers only) + one int per 64-cell chunk
 __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 64 + 8); }
 // LDS bytes of the staged vehicle table: H*KT*(2 doubles + 2 ints) + H ints (8-byte aligned)
@@ -1006,7 +1009,7 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
     chunk_cnt = (int *)after_tab;
     unsigned char *cells = after_tab + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15);
     if constexpr (USE_LDS) base = cells;
-    else base = a.gscratch + (size_t)blockIdx.x * ((size_t)W * STMPC_CELL_BYTES + (size_t)a.PW * 8);
+    else base = a.gscratch + (size_t)blockIdx.x * ((size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)a.PW * 8);
     u64 *cost = (u64 *)base;
     double *pen = (double *)(cost + W);
     unsigned *hist = (unsigned *)(pen + a.PW);
