@@ -743,37 +743,31 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
                     if (__ballot(lo + cbase + ub < hi)) {
+                        // branch-free: lanes without a candidate at this offset compute on whatever the slot holds and
+                        // then offer ~0, which a min never takes
                         double pn[UB];
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const int n = lo + cbase + ub + u;
-                            pn[u] = -1.0;
-                            if (n < hi) pn[u] = M::ldf(&pen[n & PWM]);
-                        }
+                        for (int u = 0; u < UB; ++u) pn[u] = M::ldf(&pen[(lo + cbase + ub + u) & PWM]);
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const int n = lo + cbase + ub + u;
-                            tb[ub + u] = ~0ull;
-                            if (n < hi && pn[u] >= 0.0) {                    // st_cy.pyx:383 obstacle skip
-                                const double sn = sval(n);
-                                // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
-                                const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
-                                const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
-                                const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
-                                const double dv = v - p.v_des;
-                                const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn[u];
-                                const double tot = C + ec;                   // st_cy.pyx:388
-                                tb[ub + u] = (u64)__double_as_longlong(tot);
-                                if constexpr (MODE == PASS_BOUND) { if (tb[ub + u] < my_min_tot) my_min_tot = tb[ub + u]; }
-                            }
+                            const double sn = sval(n);
+                            // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
+                            const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
+                            const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
+                            const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
+                            const double dv = v - p.v_des;
+                            const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn[u];
+                            const double tot = C + ec;                       // st_cy.pyx:388
+                            const bool ok = (n < hi) & (pn[u] >= 0.0);       // st_cy.pyx:379,383
+                            tb[ub + u] = ok ? (u64)__double_as_longlong(tot) : ~0ull;
+                            if constexpr (MODE == PASS_BOUND) { if (tb[ub + u] < my_min_tot) my_min_tot = tb[ub + u]; }
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            if (tb[ub + u] != ~0ull) {
-                                const u64 old = M::min64(&cost[(lo + cbase + ub + u) & WM], tb[ub + u]);
-                                if (old > tb[ub + u]) improved |= 1u << (ub + u);
-                                else if (old == tb[ub + u]) tied |= 1u << (ub + u);
-                            }
+                            const u64 old = M::min64(&cost[(lo + cbase + ub + u) & WM], tb[ub + u]);
+                            if (old > tb[ub + u]) improved |= 1u << (ub + u);
+                            else if (old == tb[ub + u]) tied |= 1u << (ub + u);
                         }
                     } else {
 #pragma unroll
