@@ -775,22 +775,29 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     }
                 }
                 M::barrier();     // B3: every min of this round is in
-                // stage B: the unique first setter of a cell's final value records the predecessor
+                // stage B: the unique first setter of a cell's final value records the predecessor.
+                // Read-backs are issued in groups of 4 (unconditionally) so their LDS latencies overlap.
 #pragma unroll
-                for (int u = 0; u < FANMAX; ++u) {
-                    if ((improved >> u) & 1u) {
-                        const int sl = (lo + cbase + u) & WM;
-                        if (M::ld64(&cost[sl]) == tb[u]) M::st32(&hist[sl], key);
+                for (int ub = 0; ub < FANMAX; ub += 4) {
+                    if (__ballot(((improved >> ub) & 0xFu) != 0u)) {
+                        u64 cur[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(&cost[(lo + cbase + ub + u) & WM]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(&hist[(lo + cbase + ub + u) & WM], key); }
                     }
                 }
                 M::barrier();     // B4
                 if constexpr (MODE == PASS_EXACT) {
                     // stage C: equal total cost -> the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
+                    if (__ballot(tied != 0u)) {
 #pragma unroll
-                    for (int u = 0; u < FANMAX; ++u) {
-                        if ((tied >> u) & 1u) {
-                            const int sl = (lo + cbase + u) & WM;
-                            if (M::ld64(&cost[sl]) == tb[u]) M::min32(&hist[sl], key);
+                        for (int u = 0; u < FANMAX; ++u) {
+                            if ((tied >> u) & 1u) {
+                                const int sl = (lo + cbase + u) & WM;
+                                if (M::ld64(&cost[sl]) == tb[u]) M::min32(&hist[sl], key);
+                            }
                         }
                     }
                 }
