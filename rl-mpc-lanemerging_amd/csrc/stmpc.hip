@@ -377,7 +377,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM>), grid, block, lds, st, a);                    \
         } while (0)
-#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 16); } while (0)
+#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 11); } while (0)
         if (tierLds[k]) {
             if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
             else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }
