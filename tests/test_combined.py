@@ -1,0 +1,101 @@
+"""Combined RL+ST controller decision logic against golden vectors produced by the reference's
+dqn.RLAgent.do_combined_control with a deterministic stand-in policy (tests/golden/make_golden_combined.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def stub_policy(state):
+    # same arithmetic as tests/golden/make_golden_combined.py::stub_policy
+    gap = 100.0
+    for x in state.other_xs:
+        d = x - state.ego_position[0]
+        if 0.0 <= d < gap:
+            gap = d
+    j = 0.4 * (18.0 - state.ego_speed) - 0.8 * state.ego_acceleration - 25.0 / (gap + 5.0) + 1.0
+    return max(-5.0, min(5.0, j))
+
+
+def _apply_settings(g):
+    import rl_mpc_lanemerging_amd as pkg
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    for key, val in zip(g["setting_keys"], g["setting_vals"]):
+        setattr(pkg.Settings, str(key), int(val) if str(key) in ("ROLLOUT_LENGTH", "ST_TEST_ROLLOUTS", "STOP_X") else float(val))
+    pkg.Settings.CHECK_ROLLOUT_CRASH, pkg.Settings.LIMIT_DQN_SPEED, pkg.Settings.TEST_ROLLOUT_STATE, \
+        pkg.Settings.TEST_ST_STRICTLY_BETTER = [bool(x) for x in g["flags"]]
+    return pkg
+
+
+class _S:      # minimal state for the stand-in policy on oracle structs
+    def __init__(self, st_, xs, vs):
+        self.ego_position = (st_.ego_x, st_.ego_y); self.ego_speed = st_.ego_v; self.ego_acceleration = st_.ego_a
+        self.other_xs = xs; self.other_speeds = vs
+
+
+def test_oracle_reproduces_reference_decisions(restore_settings):
+    """CPU: the decision tree restated on the oracle's predictor + solver gives the reference's decisions."""
+    from rl_mpc_lanemerging_amd import _capi
+    from rl_mpc_lanemerging_amd.combined import get_ego_speed_from_jerk
+    from oracle import st_oracle as orc
+    g = load_golden("golden_combined.npz")
+    pkg = _apply_settings(g)
+    S = pkg.Settings
+    p = _capi.Params.from_settings(S)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    n = g["ego"].shape[0]
+    reason = np.zeros(n, dtype=np.int32)
+    probe = []
+    for i in range(n):
+        k = int(g["k_count"][i])
+        st_ = orc.make_state(*g["ego"][i, :4], g["other_x"][i, :k], g["other_v"][i, :k])
+        crash, test_state, j = False, None, 0
+        while not (crash or j >= max(S.ROLLOUT_LENGTH, 1)):
+            j += 1
+            xs, vs = orc.state_lists(st_)
+            sel = get_ego_speed_from_jerk(st_.ego_v, st_.ego_a, stub_policy(_S(st_, xs, vs)))
+            st_, crash = orc.predict_with_ego(op, st_, sel, S.TICK_LENGTH, S.COMBINATION_MIN_DISTANCE)
+            if j == S.ST_TEST_ROLLOUTS:
+                test_state = st_
+            if st_.ego_x > S.STOP_X:
+                break
+        if test_state is None:
+            test_state = st_
+        if crash:
+            reason[i] = 1
+        else:
+            probe.append((i, test_state))
+    ego = np.array([[t.ego_x, t.ego_y, t.ego_v, t.ego_a, orc.ego_s(t.ego_x, t.ego_y)] for _, t in probe])
+    kc = np.array([t.k for _, t in probe], dtype=np.int32)
+    ox = np.zeros((len(probe), 8)); ov = np.zeros((len(probe), 8))
+    for r, (_, t) in enumerate(probe):
+        xs, vs = orc.state_lists(t)
+        ox[r, :t.k] = xs; ov[r, :t.k] = vs
+    res = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=8)
+    for r, (i, _) in enumerate(probe):
+        if res["crash"][r]:
+            reason[i] = 3
+    assert np.array_equal(reason, g["reason"])
+    assert np.array_equal((reason != 0).astype(np.int32), g["takeover"])
+    assert (g["reason"] == 1).sum() > 5 and (g["reason"] == 3).sum() > 5 and (g["reason"] == 0).sum() > 100
+
+
+@pytest.mark.gpu
+def test_gpu_decisions_match_reference(gpu_ctx, restore_settings):
+    from rl_mpc_lanemerging_amd import combined
+    from rl_mpc_lanemerging_amd.prediction import HighwayState
+    g = load_golden("golden_combined.npz")
+    _apply_settings(g)
+    states = []
+    for i in range(g["ego"].shape[0]):
+        k = int(g["k_count"][i])
+        states.append(HighwayState((float(g["ego"][i, 0]), float(g["ego"][i, 1])), float(g["ego"][i, 2]), float(g["ego"][i, 3]),
+                                   [float(x) for x in g["other_x"][i, :k]], [float(x) for x in g["other_v"][i, :k]], [0.0] * k))
+    d = combined.decide_batch(states, stub_policy, gpu_ctx)
+    assert np.array_equal(d["reason"], g["reason"])
+    assert np.array_equal(d["takeover"].astype(np.int32), g["takeover"])
+    # the single-state wrapper agrees and records its history like the reference's agent
+    ctl = combined.CombinedController(stub_policy)
+    for i in (0, 1, int(np.nonzero(g["takeover"])[0][0])):
+        ctl.do_combined_control(states[i])
+    assert ctl.takeover_history == [bool(g["takeover"][0]), bool(g["takeover"][1]), True]
