@@ -77,11 +77,13 @@ struct stmpc_ctx {
     size_t pool_used = 0;          // events used (multiple of 4)
     double acc_solve_ms = 0, acc_dp_ms = 0;
     int64_t acc_launches = 0, acc_fallback = 0, acc_episodes = 0;
-    int lds_tier_W[STMPC_MAX_TIERS] = {2048, 4096, 8192, 0};   // LDS windows (cells), increasing
-    int n_lds_tiers = 3;
-    int pen_cells[STMPC_MAX_TIERS] = {0, 0, 0, 0};   // STMPC_PEN_CELLS="a,b,c": penalty-buffer cells per LDS tier (0 = min(W, 4096))
+    int lds_tier_W[STMPC_MAX_TIERS] = {2048, 4096, 8192, 0, 0, 0};   // LDS windows (cells), increasing
+    int n_lds_tiers = 0;          // 0 = automatic: {2048, smallest window covering every cell (<= 8192)}
+    int pen_cells[STMPC_MAX_TIERS] = {0, 0, 0, 0, 0, 0};   // STMPC_PEN_CELLS="a,b,c": penalty-buffer cells per LDS tier (0 = min(W, 4096))
     int max_waves_per_cu = 16;
-    int waves_override = 0;       // STMPC_NW: waves per workgroup (episode) for every tier
+    int waves_override = 0;       // STMPC_NW=n or "a,b,c": waves per workgroup (episode), all tiers or per LDS tier
+    int waves_tier[STMPC_MAX_TIERS] = {0, 0, 0, 0, 0, 0};
+    bool tiers_from_env = false;
     bool allow_fastdiv = true;
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
@@ -143,6 +145,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
             if (*q == ',') ++q;
         }
         if (n > 0) c->n_lds_tiers = n;
+        c->tiers_from_env = n > 0;
     }
     if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
     if (const char *w = getenv("STMPC_PEN_CELLS")) {
@@ -155,7 +158,18 @@ int stmpc_create(stmpc_ctx **out, int device) {
             if (*q == ',') ++q;
         }
     }
-    if (const char *w = getenv("STMPC_NW")) { int v = atoi(w); if (v >= 1 && v <= STMPC_MAXWAVES) c->waves_override = v; }
+    if (const char *w = getenv("STMPC_NW")) {
+        if (strchr(w, ',')) {
+            int n = 0; const char *q = w;
+            while (*q && n < STMPC_MAX_TIERS) {
+                int v = atoi(q);
+                if (v >= 1 && v <= STMPC_MAXWAVES) c->waves_tier[n] = v;
+                ++n;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        } else { int v = atoi(w); if (v >= 1 && v <= STMPC_MAXWAVES) c->waves_override = v; }
+    }
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
@@ -169,7 +183,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->bp_tier[0],
-                     &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
+                     &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3};
     for (DevBuf *b : all) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -304,10 +318,14 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     int tierW[STMPC_MAX_TIERS]; int tierPW[STMPC_MAX_TIERS]; bool tierLds[STMPC_MAX_TIERS]; int tierGrid[STMPC_MAX_TIERS]; int tierNW[STMPC_MAX_TIERS];
     size_t tierLdsBytes[STMPC_MAX_TIERS];
     int nt = 0;
-    for (int k = 0; k < c->n_lds_tiers && nt < STMPC_MAX_TIERS - 1; ++k) {
-        int W = c->lds_tier_W[k];
+    int auto_W[2] = {2048, Wg < 8192 ? Wg : 8192};
+    int n_auto = 2;
+    if (auto_W[1] <= auto_W[0]) { auto_W[0] = auto_W[1]; n_auto = 1; }      // one window already covers the lattice
+    const int n_lds = c->tiers_from_env ? c->n_lds_tiers : n_auto;
+    for (int k = 0; k < n_lds && nt < STMPC_MAX_TIERS - 1; ++k) {
+        int W = c->tiers_from_env ? c->lds_tier_W[k] : auto_W[k];
         if (W > Wg && nt > 0) break;
-        const int nw = c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8);
+        const int nw = c->waves_tier[k] > 0 ? c->waves_tier[k] : (c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8));
         int PW = c->pen_cells[k] > 0 ? c->pen_cells[k] : 4096;         // penalty buffer: the whole window up to 4096 cells
         if (PW > W) PW = W;
         const size_t lds = (size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)PW * 8 + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) +

@@ -307,7 +307,7 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
     }
 }
 
-#define STMPC_MAX_TIERS 4
+#define STMPC_MAX_TIERS 6
 #define STMPC_CNT_ERR 63
 #define STMPC_CNT_RETRY 62
 #define STMPC_CNT_NODES_EXACT 61
