@@ -87,6 +87,7 @@ struct stmpc_ctx {
     bool allow_fastdiv = true;
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
+    double band2_mult = 5.0;       // STMPC_BAND2_MULT
     double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
     bool allow_stage_tab = true;   // STMPC_STAGE_TAB=0: read the vehicle table from HBM/L2 instead of staging it in LDS
     int last_nt = 0;
@@ -173,6 +174,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
+    if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
     if (const char *w = getenv("STMPC_SKIP_FRAC")) c->skip_frac = atof(w);
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     *out = c;
@@ -379,6 +381,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // weights; measured optimum of a 60..1200 sweep on the H=40 workload); any value is safe (the exact pass
     // re-checks), it only trades pre-pass work for tightness of the bound
     a.band = c->band_override > 0 ? c->band_override : fmax(1.0, 0.5 * dp.v_w * dp.v_des * dp.v_des);
+    a.band2_mult = c->band2_mult;
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
     HIPCHK(hipEventRecord(e1, st));

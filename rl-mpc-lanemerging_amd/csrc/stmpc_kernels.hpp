@@ -323,6 +323,7 @@ struct SolveArgs {
     int last_tier;         // overflow here is an internal error
     int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
     double band;           // cost band of the pre-pass
+    double band2_mult;     // the second pre-pass attempt (penalty zone allowed) uses band * band2_mult
     int skip_span;         // forward an episode to the next tier without an exact pass when its pre-pass already spanned this many cells (0 = never)
     // table mode inputs
     const double *ego;     // [N][5]
@@ -891,7 +892,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             int bspan = out.maxspan;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             else {
-                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * 20.0, false, out);
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
                 bn += out.nodes;
                 bspan = out.maxspan;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
