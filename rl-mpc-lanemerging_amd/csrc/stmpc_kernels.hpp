@@ -914,8 +914,9 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
         if (out.best_t == H - 1 || !out.pruned) break;
         // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
+        // (its answer is usually within a few per cent of the bound, so grow gently first)
         if (attempt >= 3) ubits = INF_BITS;
-        else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * 1.25);
+        else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * (attempt == 0 ? 1.02 : (attempt == 1 ? 1.08 : 1.3)));
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);
     }
     const int best_t = out.best_t, best_n = out.best_n;
