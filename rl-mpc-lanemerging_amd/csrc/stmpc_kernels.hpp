@@ -339,7 +339,10 @@ struct SolveArgs {
     unsigned char *gscratch;   // HBM-storage variant: [blocks][20*W] bytes
     unsigned *counters;    // [0] tier-0 work counter; [4k] list-k length, [4k+1] list-k work counter; [63] error flag
     int *lists;            // [STMPC_MAX_TIERS][N] episode ids queued for tier k
-    u64 *ubound;           // [N] cost bound an episode had when it overflowed a tier (handed to the next tier)
+    u64 *ubound;           // [N] cost bound of an episode: written by the bound-only phase / on overflow of a tier
+    int phase;             // 0: bound + exact in one go; 1: bounding pre-passes only (writes ubound, proxy); 2: exact, bound from ubound
+    const int *order;      // tier-0 episode order for phase 2 (heaviest first) or null
+    unsigned *proxy;       // [N] work estimate written by phase 1 (nodes the pre-passes expanded)
     // outputs
     int *path_idx;         // [N][H]
     int *best_t;           // [N]
@@ -881,7 +884,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     u64 ubits = INF_BITS;
     bool have_bound = false;
     if constexpr (!GRID) {
-        if (a.prune && a.tier > 0) {          // the previous tier already bounded this episode before it overflowed
+        if (a.prune && (a.tier > 0 || a.phase == 2)) {   // bounded earlier (bound-only phase, or the tier it overflowed)
             const u64 ub = a.ubound[e];
             if (ub != 0ull) { ubits = ub; have_bound = true; }
         }
@@ -898,6 +901,13 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
+            if (a.phase == 1) {                               // bound-only phase: publish the bound and a work estimate
+                if (tid == 0) {
+                    a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
+                    a.proxy[e] = (ubits == INF_BITS) ? 0x3fffffffu : (unsigned)bn;     // unbounded episodes are the heaviest
+                }
+                return 0;
+            }
             // the exact pass explores a superset of the pre-pass: if that one was already wide, do not start here
             if (!a.last_tier && a.skip_span > 0 && (rc != 0 || bspan > a.skip_span)) {
                 if (tid == 0) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
@@ -1028,8 +1038,8 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
             if (tid == 0) {
                 int e = -1;
                 if (a.tier == 0) {
-                    unsigned w = atomicAdd(&a.counters[0], 1u);
-                    if (w < (unsigned)a.N) e = (int)w;
+                    unsigned w = atomicAdd(&a.counters[a.phase == 1 ? 2 : 0], 1u);
+                    if (w < (unsigned)a.N) e = a.order ? a.order[w] : (int)w;
                 } else {
                     unsigned w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
                     unsigned cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1051,6 +1061,28 @@ __global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
             }
         }
     }
+}
+
+// Heaviest-first order of the episodes for the exact phase (LPT): counting sort of the work estimates into
+// 64 logarithmic buckets, one workgroup.
+__global__ void __launch_bounds__(1024) k_order(int N, const unsigned *__restrict__ proxy, int *__restrict__ order) {
+    __shared__ unsigned cnt[64], off[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) cnt[tid] = 0u;
+    __syncthreads();
+    auto bucket = [](unsigned v) -> int {       // 2 buckets per octave, descending work
+        v += 1u;
+        const int l = 31 - __clz((int)v);
+        const int half = (l > 0) ? (int)((v >> (l - 1)) & 1u) : 0;
+        int b = 2 * l + half;
+        b = b > 63 ? 63 : b;
+        return 63 - b;
+    };
+    for (int e = tid; e < N; e += blockDim.x) atomicAdd(&cnt[bucket(proxy[e])], 1u);
+    __syncthreads();
+    if (tid == 0) { unsigned acc = 0; for (int b = 0; b < 64; ++b) { off[b] = acc; acc += cnt[b]; } }
+    __syncthreads();
+    for (int e = tid; e < N; e += blockDim.x) { const unsigned pos = atomicAdd(&off[bucket(proxy[e])], 1u); order[pos] = e; }
 }
 
 // Materialise the reference's grids for one state (st.py:25-70), from the car table of episode 0.
