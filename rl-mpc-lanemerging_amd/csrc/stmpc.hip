@@ -90,7 +90,7 @@ struct stmpc_ctx {
     double band2_mult = 5.0;       // STMPC_BAND2_MULT
     bool two_phase = false;        // STMPC_TWO_PHASE=1: bound all episodes first, then solve heaviest-first (measured 6 % slower at N=4096)
     double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
-    bool allow_stage_tab = true;   // STMPC_STAGE_TAB=0: read the vehicle table from HBM/L2 instead of staging it in LDS
+    bool allow_stage_tab = false;  // STMPC_STAGE_TAB=1: stage the vehicle table in LDS + scalar registers (costs the 4th workgroup per CU)
     int last_nt = 0;
     bool last_has_hbm = true;
 };
@@ -332,7 +332,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         int W = c->tiers_from_env ? c->lds_tier_W[k] : auto_W[k];
         if (W > Wg && nt > 0) break;
         const int nw = c->waves_tier[k] > 0 ? c->waves_tier[k] : (c->waves_override > 0 ? c->waves_override : (W <= 2048 ? 4 : 8));
-        int PW = c->pen_cells[k] > 0 ? c->pen_cells[k] : 4096;         // penalty buffer: the whole window up to 4096 cells
+        // penalty buffer: 1024 cells for the first (4-wave) tier -- with the 14 B/cell arrays that is 38 KB per
+        // workgroup, i.e. 4 workgroups = 16 waves per CU -- and up to 4096 cells for the wider tiers
+        int PW = c->pen_cells[k] > 0 ? c->pen_cells[k] : (k == 0 && W <= 2048 ? 1024 : 4096);
         if (PW > W) PW = W;
         const size_t lds = (size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)PW * 8 + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15) +
                            stmpc_tab_bytes(H, stage_tab ? 8 : 0);

@@ -1006,7 +1006,7 @@ __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_
 
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
-__global__ void __launch_bounds__(512) k_solve(SolveArgs a) {
+__global__ void __launch_bounds__(512, (FANMAX <= 11 ? 4 : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;
