@@ -88,6 +88,7 @@ struct stmpc_ctx {
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
     double band2_mult = 5.0;       // STMPC_BAND2_MULT
+    bool force_general = false;    // STMPC_FORCE_GENERAL=1 (tests)
     bool two_phase = false;        // STMPC_TWO_PHASE=1: bound all episodes first, then solve heaviest-first (measured 6 % slower at N=4096)
     double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
     bool allow_stage_tab = false;  // STMPC_STAGE_TAB=1: stage the vehicle table in LDS + scalar registers (costs the 4th workgroup per CU)
@@ -175,6 +176,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_FASTDIV")) c->allow_fastdiv = atoi(w) != 0;
     if (const char *w = getenv("STMPC_PRUNE")) c->prune = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND")) c->band_override = atof(w);
+    if (const char *w = getenv("STMPC_FORCE_GENERAL")) c->force_general = atoi(w) != 0;
     if (const char *w = getenv("STMPC_TWO_PHASE")) c->two_phase = atoi(w) != 0;
     if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
     if (const char *w = getenv("STMPC_SKIP_FRAC")) c->skip_frac = atof(w);
@@ -388,6 +390,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // re-checks), it only trades pre-pass work for tightness of the bound
     a.band = c->band_override > 0 ? c->band_override : fmax(1.0, 0.5 * dp.v_w * dp.v_des * dp.v_des);
     a.band2_mult = c->band2_mult;
+    a.force_general = c->force_general ? 1 : 0;
     a.proxy = c->proxy.as<unsigned>();
     const bool two_phase = a.prune && c->two_phase;      // bound all episodes first, then solve them heaviest-first
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
@@ -404,13 +407,15 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
         const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
-#define STMPC_LAUNCH(L, FD, KT_, FM)                                                                          \
+#define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
             if (lds > 48 * 1024)                                                                              \
-                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM>,                      \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG>,                  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM>), grid, block, lds, st, a);                    \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG>), grid, block, lds, st, a);                \
         } while (0)
+        // only the last tier carries the general lattice-coordinate form (see solve_episode)
+#define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
 #define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 11); } while (0)
         if (tierLds[k]) {
             if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
@@ -425,6 +430,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
             continue;
         }
 #undef STMPC_LAUNCH
+#undef STMPC_LAUNCH_S
         if ((need_hbm_tier && k == nt - 2) || (!need_hbm_tier && k == nt - 1) || nt == 1) HIPCHK(hipEventRecord(e2, st));   // after the last LDS tier
     }
     HIPCHK(hipEventRecord(e3, st));
@@ -568,7 +574,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
     a.s_sequence = c->s_misc3.as<double>();
-    hipLaunchKernelGGL((k_solve<false, true, false, 0, 16>), dim3(1), dim3(256), ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16, nullptr, a);
+    hipLaunchKernelGGL((k_solve<false, true, false, 0, 16, true>), dim3(1), dim3(256), ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16, nullptr, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));

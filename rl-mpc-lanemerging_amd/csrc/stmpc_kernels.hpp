@@ -340,6 +340,7 @@ struct SolveArgs {
     unsigned *counters;    // [0] tier-0 work counter; [4k] list-k length, [4k+1] list-k work counter; [63] error flag
     int *lists;            // [STMPC_MAX_TIERS][N] episode ids queued for tier k
     u64 *ubound;           // [N] cost bound of an episode: written by the bound-only phase / on overflow of a tier
+    int force_general;     // test hook: route every episode to the last tier as if its lattice were not affine
     int phase;             // 0: bound + exact in one go; 1: bounding pre-passes only (writes ubound, proxy); 2: exact, bound from ubound
     const int *order;      // tier-0 episode order for phase 2 (heaviest first) or null
     unsigned *proxy;       // [N] work estimate written by phase 1 (nodes the pre-passes expanded)
@@ -446,7 +447,7 @@ enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 //   -- barrier --
 //   C  candidates that met an equal value and still match the final cost: atomic_min(hist[cell], key);
 //      key has the predecessor index in the high half, so the smaller predecessor wins (st_cy.pyx:388 order)
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
                        u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
                        u64 ubits, double band, bool hardsoft, PassOut &out) {
@@ -468,7 +469,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         if constexpr (GRID) return a.s_values[n];
         else {
             double v = start_s + (double)n * delta;      // numpy arange: a[i>=2] = start + i*delta
-            if (!s1_plain) { if (n == 1) v = s1; }       //               a[1]    = start + step
+            if constexpr (S1GEN) { if (!s1_plain) { if (n == 1) v = s1; } }   //  a[1] = start + step (S1GEN=false: caller guarantees they coincide)
             return v;
         }
     };
@@ -831,7 +832,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 }
 
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
                              double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n) {
     const DevP &p = a.p;
@@ -854,6 +855,11 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     ep.est_prev = ep.start_s - ep.v0 * dt;
     ep.est_second = ep.est_prev - dt * (ep.v0 - ep.a0 * dt);
     ep.s1_plain = (ep.start_s + 1.0 * ep.delta == ep.s1);
+    if constexpr (!S1GEN) {
+        // this variant evaluates s_values[n] as start + n*delta for every n; the (very rare) episode whose second
+        // lattice point start+step differs from that goes to the last tier, which is compiled with the general form
+        if ((!ep.s1_plain || a.force_general) && a.phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
+    }
     ep.bp = a.bp + (size_t)slot * H * W;
     const double start_s = ep.start_s, delta = ep.delta;
     const int S = ep.S;
@@ -890,12 +896,12 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
         if (a.prune && !have_bound) {
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
-            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
+            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
             int bspan = out.maxspan;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             else {
-                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
                 bn += out.nodes;
                 bspan = out.maxspan;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
@@ -916,7 +922,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
     }
     for (int attempt = 0;; ++attempt) {
-        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out);
+        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out);
         if (rc != 0) {
             if constexpr (!GRID) { if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits; }   // 0 is reserved for "unknown"
             return rc;
@@ -1005,7 +1011,7 @@ __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 
 __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_t)H * KT * 24 + (((size_t)H * 4 + 7) & ~(size_t)7); }
 
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
 __global__ void __launch_bounds__(512, (FANMAX <= 11 ? 4 : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
@@ -1029,7 +1035,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 11 ? 4 : 2)) k_solve(SolveArgs
     u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
-        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
+        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX, true>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
         if (rc != 0 && tid == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
@@ -1050,7 +1056,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 11 ? 4 : 2)) k_solve(SolveArgs
             __syncthreads();
             const int e = sh.work;
             if (e < 0) break;
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);

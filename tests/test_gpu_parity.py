@@ -74,6 +74,21 @@ def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
     ctx.close()
 
 
+def test_general_lattice_form_routing(restore_settings, monkeypatch):
+    """Episodes whose lattice is not start + n*delta (not reachable through np.arange, but guarded) are sent to the
+    last tier, which evaluates the general form: force that route for every episode and compare."""
+    from rl_mpc_lanemerging_amd import _capi, st
+    monkeypatch.setenv("STMPC_FORCE_GENERAL", "1")
+    ctx = _capi.Context(0)
+    for fname in ("golden_default.npz", "golden_h40a21.npz"):
+        g = load_golden(fname)
+        p, op = settings_from_golden(g)
+        res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
+        _check(res, g, g["t_values"].size)
+        assert ctx.stats()["fast_path"] == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("tiers", ["64", "256,512", "512,2048", "64,128,256"])
 @pytest.mark.parametrize("fastdiv", ["1", "0"])
 def test_window_overflow_falls_back_exactly(tiers, fastdiv, restore_settings, monkeypatch):
