@@ -474,6 +474,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
     };
     u16 *bp = ep.bp;
+    struct { double kv, ka, kj, invK; bool ok; } nk;        // coefficients of the edge-cost quadratic (see the candidate filter)
+    nk.kv = p.v_w / dt2; nk.ka = p.a_w / (dt2 * dt2); nk.kj = p.j_w / (dt3 * dt3);
+    nk.invK = 1.0 / (nk.kv + nk.ka + nk.kj);
+    nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
+    auto two_sv_n = [](double x) -> double { return 2.0 * x; };
 
     M::barrier();                       // previous users of the arrays are done
     if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
@@ -660,6 +665,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             int lo = 0, hi = 0;
             unsigned key = 0u;        // what a target won by this source stores: i << 16 | p1 index
             int pr = 0;
+            bool cut_l = false;
             if (inlist) {
                 sv = sval(i);
                 if (t == 0) { p1 = ep.est_prev; p2 = ep.est_second; key = 0u; }      // st_cy.pyx:342
@@ -689,9 +695,37 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     lo = mi; hi = ma + 1;
                     if (hi > S) hi = S;                                      // st_cy.pyx:379
                     if (lo < i) lo = i;                                      // cannot happen (min_v >= 0); keeps the in-place invariant
+                    if constexpr (MODE == PASS_EXACT) {
+                        // Candidates that cannot stay within the bound are not evaluated.  Without the gap penalty (>= 0)
+                        // the edge cost is a quadratic in the candidate position s_n (st_cy.pyx:46-50):
+                        //   k_v (s_n - c_v)^2 + k_a (s_n - c_a)^2 + k_j (s_n - c_j)^2  <=  U - C
+                        // holds on an interval around its minimiser.  This is a conservative filter (inflated slack, one
+                        // cell of margin on each side, where the quadratic already exceeds the slack by K*delta^2), so
+                        // every candidate it drops has total cost > U; whatever it keeps is evaluated exactly as before.
+                        if (nk.ok && ubits < INF_BITS && hi > lo) {
+                            const double slack = (__longlong_as_double((long long)ubits) - C) * (1.0 + 1e-9) + 1e-9;
+                            const double c_v = sv + p.v_des * dt, c_a = two_sv_n(sv) - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
+                            const double num = nk.kv * c_v + nk.ka * c_a + nk.kj * c_j;
+                            const double smin_ = num * nk.invK;
+                            const double emin = nk.kv * (c_v - smin_) * (c_v - smin_) + nk.ka * (c_a - smin_) * (c_a - smin_) +
+                                                nk.kj * (c_j - smin_) * (c_j - smin_);
+                            const double room = slack - emin;
+                            if (!(room >= 0.0)) { if (hi > lo) cut_l = true; lo = 0; hi = 0; }
+                            else {
+                                const double rad = sqrt(room * nk.invK);
+                                const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
+                                const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
+                                const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
+                                const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                                if (nlo_ > lo || nhi_ < hi) cut_l = true;
+                                lo = nlo_; hi = nhi_;
+                            }
+                        }
+                    }
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
             }
+            if constexpr (MODE == PASS_EXACT) { if (__ballot(cut_l) && lane == 0) atomicOr(&sh.flags, 1); }
             if (relax) {
                 const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
                 const int fan_w = wave_max_i(hi - lo);
