@@ -317,7 +317,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // widest fan-out the dynamics allow (st_cy.pyx:65-93): acceleration- or jerk-limited window, +2 for rounding
     const double fan_acc = (dp.a_max - dp.a_min) * dp.dt2 / dp.ds, fan_jerk = (dp.j_max - dp.j_min) * dp.dt3 / dp.ds;
     const double fan_bound = (fan_acc < fan_jerk ? fan_acc : fan_jerk) + 2.0;
-    const bool small_fan = fan_bound <= 8.0;
+    const bool small_fan = fan_bound <= 9.0;
     // the scalar-register vehicle table costs ~48 SGPRs/VGPRs: only with the small-fan kernel (the wide one would spill)
     const bool stage_tab = c->allow_stage_tab && small_fan && Kalloc <= 8 && stmpc_tab_bytes(H, 8) <= 4096;
 
@@ -416,7 +416,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
-#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 8); else STMPC_LAUNCH(L, FD, KT_, 11); } while (0)
+#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 9); else STMPC_LAUNCH(L, FD, KT_, 12); } while (0)
         if (tierLds[k]) {
             if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
             else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }

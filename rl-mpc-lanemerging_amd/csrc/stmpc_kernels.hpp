@@ -778,7 +778,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
-                constexpr int UB = (FANMAX % 8 == 0) ? 8 : (FANMAX % 11 == 0 ? 11 : FANMAX);
+                constexpr int UB = (FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX);   // small batches: slots beyond a wave's widest range are skipped
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
                     if (__ballot(lo + cbase + ub < hi)) {
@@ -1046,7 +1046,7 @@ __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_
 
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
-__global__ void __launch_bounds__(512, (FANMAX <= 11 ? 4 : 2)) k_solve(SolveArgs a) {
+__global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;
