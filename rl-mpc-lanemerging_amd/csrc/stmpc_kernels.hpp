@@ -722,6 +722,24 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             }
                         }
                     }
+                    if constexpr (MODE == PASS_BOUND) {
+                        // Heuristic counterpart for the pre-pass: a child whose quadratic cost exceeds the source's best by
+                        // more than the band would fall outside the next layer's band anyway (the pre-pass may drop
+                        // anything; it only has to find some complete path).
+                        if (nk.ok && hi > lo) {
+                            const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
+                            const double smin_ = (nk.kv * c_v + nk.ka * c_a + nk.kj * c_j) * nk.invK;
+                            const double rad = sqrt(1.25 * band * nk.invK);
+                            const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
+                            const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
+                            const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
+                            const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                            // never drop everything: a source whose whole window lies off the minimiser keeps its nearest end
+                            if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
+                            else if (nlo_ >= hi) { lo = hi - 1; }
+                            else { hi = lo + 1; }
+                        }
+                    }
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
             }
