@@ -6,15 +6,20 @@
 //               vehicles that obstruct the lattice (st.py:44-65): front/back edge and the
 //               blocked index window.  The H x S obstacle / distance grids of the reference
 //               are never materialised.
-//   k_solve   : one WAVEFRONT (64 lanes) per episode, persistent blocks pulling episodes from
-//               a device work counter.  Layer-synchronous forward DP that is equivalent to the
-//               reference's heap Dijkstra (st_cy.pyx:315-399): lanes stripe over the source
-//               nodes of a layer, each lane relaxes its node's <=A candidate cells into the
-//               next layer with an exact (cost, predecessor-index) minimum built from
-//               ds_min_rtn_u64 on the fp64 bit pattern plus an in-order fix-up of the
-//               predecessor (valid because one wave owns the episode and LDS is in-order per
-//               wave).  Layers live in circular LDS windows of W cells; an episode whose
-//               reachable span exceeds W is queued for the HBM-scratch variant of the same code.
+//   k_solve   : one WORKGROUP (4 or 8 wavefronts) per episode, persistent workgroups pulling episodes
+//               from a device work counter.  Layer-synchronous forward DP that is equivalent to the
+//               reference's heap Dijkstra (st_cy.pyx:315-399).  Per layer the waves compact the nodes
+//               to expand into a descending list and consume it in rounds of 64 sources per wave;
+//               each lane relaxes its node's candidate cells into the next layer with an exact
+//               (cost, predecessor-index) minimum: ds_min_rtn_u64 on the fp64 bit pattern, then --
+//               separated by workgroup barriers -- the unique first setter of a cell's final value
+//               writes the predecessor key and equal-cost candidates ds_min_u32 it.  One circular LDS
+//               window of W cells holds both the layer being expanded and the one being built
+//               (sources are consumed top-down and every edge points upward).  A cheap banded
+//               pre-pass bounds the terminal cost; the exact pass then expands only nodes within the
+//               bound and evaluates only candidates that can stay within it.  An episode whose live
+//               span exceeds W is queued, with its bound, for a tier with a larger window (LDS up to
+//               8192 cells, else HBM scratch; same code).
 //
 // Everything is fp64 and compiled with -ffp-contract=off: one IEEE op per reference op.
 #pragma once
