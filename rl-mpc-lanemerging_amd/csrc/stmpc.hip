@@ -90,7 +90,6 @@ struct stmpc_ctx {
     double band2_mult = 5.0;       // STMPC_BAND2_MULT
     bool force_general = false;    // STMPC_FORCE_GENERAL=1 (tests)
     bool two_phase = false;        // STMPC_TWO_PHASE=1: bound all episodes first, then solve heaviest-first (measured 6 % slower at N=4096)
-    double skip_frac = 0.0;        // STMPC_SKIP_FRAC: see SolveArgs::skip_span
     bool allow_stage_tab = false;  // STMPC_STAGE_TAB=1: stage the vehicle table in LDS + scalar registers (costs the 4th workgroup per CU)
     int last_nt = 0;
     bool last_has_hbm = true;
@@ -179,7 +178,6 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_FORCE_GENERAL")) c->force_general = atoi(w) != 0;
     if (const char *w = getenv("STMPC_TWO_PHASE")) c->two_phase = atoi(w) != 0;
     if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
-    if (const char *w = getenv("STMPC_SKIP_FRAC")) c->skip_frac = atof(w);
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     *out = c;
     return STMPC_OK;
@@ -402,7 +400,6 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.phase = bound_phase ? 1 : (two_phase ? 2 : 0);
         a.order = (!bound_phase && two_phase && k == 0) ? c->order.as<int>() : nullptr;
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
-        a.skip_span = (int)(c->skip_frac * tierW[k]);
         a.bp = c->bp_tier[k].as<u16>();
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];

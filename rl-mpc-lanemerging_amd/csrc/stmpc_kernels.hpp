@@ -29,7 +29,6 @@
 typedef unsigned long long u64;
 typedef unsigned short u16;
 
-#define STMPC_WAVE 64
 #define STMPC_MAXH 64
 
 namespace stmpc {
@@ -329,7 +328,6 @@ struct SolveArgs {
     int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
     double band;           // cost band of the pre-pass
     double band2_mult;     // the second pre-pass attempt (penalty zone allowed) uses band * band2_mult
-    int skip_span;         // forward an episode to the next tier without an exact pass when its pre-pass already spanned this many cells (0 = never)
     // table mode inputs
     const double *ego;     // [N][5]
     CarTab tab;
@@ -380,12 +378,6 @@ struct Mem {
     static __device__ __forceinline__ void barrier() {
         if constexpr (USE_LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
-    }
-    // order this wave's own accesses: LDS is in-order per wave (a compiler barrier suffices);
-    // the HBM variant drains the vector-memory queue.
-    static __device__ __forceinline__ void order() {
-        if constexpr (USE_LDS) __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 };
 
@@ -483,7 +475,6 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     nk.kv = p.v_w / dt2; nk.ka = p.a_w / (dt2 * dt2); nk.kj = p.j_w / (dt3 * dt3);
     nk.invK = 1.0 / (nk.kv + nk.ka + nk.kj);
     nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
-    auto two_sv_n = [](double x) -> double { return 2.0 * x; };
 
     M::barrier();                       // previous users of the arrays are done
     if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
@@ -709,7 +700,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         // every candidate it drops has total cost > U; whatever it keeps is evaluated exactly as before.
                         if (nk.ok && ubits < INF_BITS && hi > lo) {
                             const double slack = (__longlong_as_double((long long)ubits) - C) * (1.0 + 1e-9) + 1e-9;
-                            const double c_v = sv + p.v_des * dt, c_a = two_sv_n(sv) - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
+                            const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
                             const double num = nk.kv * c_v + nk.ka * c_a + nk.kj * c_j;
                             const double smin_ = num * nk.invK;
                             const double emin = nk.kv * (c_v - smin_) * (c_v - smin_) + nk.ka * (c_a - smin_) * (c_a - smin_) +
@@ -955,12 +946,10 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
             int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
-            int bspan = out.maxspan;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             else {
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
                 bn += out.nodes;
-                bspan = out.maxspan;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
@@ -970,11 +959,6 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                     a.proxy[e] = (ubits == INF_BITS) ? 0x3fffffffu : (unsigned)bn;     // unbounded episodes are the heaviest
                 }
                 return 0;
-            }
-            // the exact pass explores a superset of the pre-pass: if that one was already wide, do not start here
-            if (!a.last_tier && a.skip_span > 0 && (rc != 0 || bspan > a.skip_span)) {
-                if (tid == 0) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
-                return 1;
             }
         }
     }
