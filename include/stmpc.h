@@ -11,6 +11,8 @@
  *                                independent HighwayState's (prediction.py:9-20), plus the path-distance probe of
  *                                st.test_guaranteed_crash_from_state (st.py:790-802)
  *   stmpc_predict_batch       <- HighwayState.predict_step_with_ego / predict_step_without_ego (prediction.py:22-105)
+ *   stmpc_finer_fit_batch     <- st.finer_fit                        st.py:584-723 (QP via cvxopt.solvers.qp, st.py:16-17,722)
+ *   stmpc_st_control_batch[_device] <- st.do_st_control              st.py:757-783 applied to N independent states
  *   stmpc_ego_s               <- control.get_ego_s                   control.py:373-380
  *   stmpc_num_s / stmpc_num_t <- the np.arange sizes at st.py:31-32
  *
@@ -173,6 +175,42 @@ int stmpc_predict_batch(stmpc_ctx *ctx, const stmpc_params *p, int mode, int N, 
                         const double *other_v, const double *selected_speed, double dt,
                         double min_crash_distance, double *ego4_out, double *other_x_out,
                         double *other_v_out, int32_t *crashed);
+
+#define STMPC_QP_NMAX     64   /* max fine samples of st.finer_fit (one wavefront lane per sample) */
+#define STMPC_QP_MAXITERS 10   /* solvers.options['maxiters'] = 10, st.py:17 */
+
+/*
+ * st.finer_fit (st.py:584-723), batched, HOST pointers: re-samples coarse ST paths (planning step coarse_delta_t)
+ * to the simulator tick delta_t by the reference's QP: minimise |x - interp(s)|^2 subject to x_0 = s_0 and speed /
+ * acceleration / jerk limits written as finite differences (limits from p: v_max, a_max, a_min, j_max, j_min),
+ * solved with cvxopt's coneqp iteration capped at maxiters (the reference uses STMPC_QP_MAXITERS).
+ *   s_seq   [N][Hs]  coarse paths, row i valid for len[i] entries (1 <= len[i] <= Hs <= 64)
+ *   v0, a0  [N]      start_speed, start_acceleration
+ *   bac     [N][4] or NULL: before_s, before_speed, after_s, after_speed (st.py:672-702; +-inf = no such car)
+ *   out     [N][n_max] fine paths;  out_len [N] their lengths: 1 when len[i] == 1 (returned as is, st.py:587-588),
+ *           -1 when the fine grid would have more than STMPC_QP_NMAX samples (nothing written)
+ *   iters   [N] or NULL: iterations done, negated when the cap was reached without meeting cvxopt's tolerances
+ */
+int stmpc_finer_fit_batch(stmpc_ctx *ctx, const stmpc_params *p, double delta_t, double coarse_delta_t, int maxiters,
+                          int N, int Hs, const double *s_seq, const int32_t *len, const double *v0, const double *a0,
+                          const double *bac, int n_max, double *out, int32_t *out_len, int32_t *iters);
+
+/*
+ * st.do_st_control (st.py:757-783) for N states: lattice search, trailing-zero trim, QP re-sampling when
+ * tick_length < p->dt (st.py:771-772), commanded speed (x_1 - x_0) / tick_length, or the current speed when the
+ * path has a single point (st.py:775-777).  Inputs as stmpc_solve_batch.  Outputs: speed [N]; best_t [N]
+ * (best_t < H-1 <=> "ST Solver finds crash inevitable", st.py:765-766); optional path_idx [N][H], cost [N],
+ * fine [N][STMPC_QP_NMAX] + fine_len [N] (the re-sampled path).  The _device form takes device pointers
+ * (path_idx, best_t, cost required as scratch) and is asynchronous on `stream`.
+ */
+int stmpc_st_control_batch(stmpc_ctx *ctx, const stmpc_params *p, double tick_length, int N, int Kmax,
+                           const double *ego, const int32_t *k_count, const double *other_x, const double *other_v,
+                           double *speed, int32_t *best_t, int32_t *path_idx, double *cost, double *fine,
+                           int32_t *fine_len);
+int stmpc_st_control_batch_device(stmpc_ctx *ctx, const stmpc_params *p, double tick_length, int N, int Kmax,
+                                  const double *d_ego, const int32_t *d_k_count, const double *d_other_x,
+                                  const double *d_other_v, int32_t *d_path_idx, int32_t *d_best_t, double *d_cost,
+                                  double *d_speed, double *d_fine, int32_t *d_fine_len, void *stream);
 
 /* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
  * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b) HOST pointers. */

@@ -61,7 +61,11 @@ EXPORTS = (
     "stmpc_backend_info", "stmpc_last_error", "stmpc_create", "stmpc_destroy", "stmpc_ego_s", "stmpc_num_s",
     "stmpc_num_t", "stmpc_path_mean_abs_jerk", "stmpc_solve_batch_device", "stmpc_solve_batch", "stmpc_get_stats",
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
+    "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
 )
+
+QP_NMAX = 64        # STMPC_QP_NMAX
+QP_MAXITERS = 10    # STMPC_QP_MAXITERS (solvers.options['maxiters'], st.py:17)
 
 
 def lib_path():
@@ -101,6 +105,10 @@ def load():
                                         dp, dp, dp, ip]
     lib.stmpc_probe_arith.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.stmpc_profile.argtypes = [vp, C.c_int, C.POINTER(ProfileTotals)]
+    lib.stmpc_finer_fit_batch.argtypes = [vp, pp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp,
+                                          C.c_int, dp, ip, ip]
+    lib.stmpc_st_control_batch.argtypes = [vp, pp, C.c_double, C.c_int, C.c_int, dp, ip, dp, dp, dp, ip, ip, dp, dp, ip]
+    lib.stmpc_st_control_batch_device.argtypes = [vp, pp, C.c_double, C.c_int, C.c_int] + [vp] * 10 + [vp]
     _lib = lib
     return lib
 
@@ -189,6 +197,61 @@ class Context:
         self._chk(self._lib.stmpc_solve_batch_device(self._h, C.byref(params), int(N), int(Kmax), d_ego, d_k, d_ox,
                                                      d_ov, d_path, d_bt, d_cost, d_pd or None, d_crash or None,
                                                      stream or None))
+
+    # -- st.finer_fit, batched (host arrays) ------------------------------------------------------
+    def finer_fit_batch(self, params, delta_t, coarse_delta_t, s_seq, lengths, v0, a0, bac=None, maxiters=QP_MAXITERS):
+        """Returns ``(out[N, QP_NMAX], out_len[N], iters[N])``; see ``stmpc_finer_fit_batch`` in include/stmpc.h."""
+        s_seq = np.ascontiguousarray(s_seq, dtype=np.float64)
+        if s_seq.ndim != 2:
+            raise ValueError("s_seq must be [N, Hs]")
+        N, Hs = s_seq.shape
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        v0 = np.ascontiguousarray(v0, dtype=np.float64)
+        a0 = np.ascontiguousarray(a0, dtype=np.float64)
+        if bac is not None:
+            bac = np.ascontiguousarray(bac, dtype=np.float64).reshape(N, 4)
+        out = np.zeros((N, QP_NMAX), dtype=np.float64)
+        out_len = np.zeros(N, dtype=np.int32)
+        iters = np.zeros(N, dtype=np.int32)
+        self._chk(self._lib.stmpc_finer_fit_batch(self._h, C.byref(params), float(delta_t), float(coarse_delta_t),
+                                                  int(maxiters), N, Hs, _dptr(s_seq), _iptr(lengths), _dptr(v0), _dptr(a0),
+                                                  _dptr(bac), QP_NMAX, _dptr(out), _iptr(out_len), _iptr(iters)))
+        return out, out_len, iters
+
+    # -- st.do_st_control, batched (host arrays) ---------------------------------------------------
+    def st_control_batch(self, params, tick_length, ego, k_count, other_x, other_v, want_paths=False):
+        """Returns a dict: ``speed[N]``, ``best_t[N]`` and, with ``want_paths``, ``path_idx``, ``cost``, ``fine``, ``fine_len``."""
+        ego = np.ascontiguousarray(ego, dtype=np.float64)
+        k_count = np.ascontiguousarray(k_count, dtype=np.int32)
+        N = ego.shape[0]
+        if ego.ndim != 2 or ego.shape[1] != 5:
+            raise ValueError("ego must be [N,5] (x, y, v, a, start_s)")
+        other_x = np.ascontiguousarray(other_x, dtype=np.float64)
+        other_v = np.ascontiguousarray(other_v, dtype=np.float64)
+        Kmax = other_x.shape[1] if other_x.ndim == 2 else (other_x.size // N if N else 0)
+        other_x = other_x.reshape(N, Kmax)
+        other_v = other_v.reshape(N, Kmax)
+        H = num_t(params)
+        speed = np.zeros(N, dtype=np.float64)
+        best_t = np.zeros(N, dtype=np.int32)
+        path = np.empty((N, H), dtype=np.int32) if want_paths else None
+        cost = np.empty(N, dtype=np.float64) if want_paths else None
+        fine = np.zeros((N, QP_NMAX), dtype=np.float64) if want_paths else None
+        fine_len = np.zeros(N, dtype=np.int32) if want_paths else None
+        self._chk(self._lib.stmpc_st_control_batch(self._h, C.byref(params), float(tick_length), N, Kmax, _dptr(ego),
+                                                   _iptr(k_count), _dptr(other_x) if Kmax else None,
+                                                   _dptr(other_v) if Kmax else None, _dptr(speed), _iptr(best_t),
+                                                   _iptr(path), _dptr(cost), _dptr(fine), _iptr(fine_len)))
+        res = {"speed": speed, "best_t": best_t}
+        if want_paths:
+            res.update(path_idx=path, cost=cost, fine=fine, fine_len=fine_len)
+        return res
+
+    def st_control_batch_device(self, params, tick_length, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_speed,
+                                d_fine=0, d_fine_len=0, stream=0):
+        self._chk(self._lib.stmpc_st_control_batch_device(self._h, C.byref(params), float(tick_length), int(N), int(Kmax),
+                                                          d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_speed,
+                                                          d_fine or None, d_fine_len or None, stream or None))
 
     def profile_begin(self):
         self._chk(self._lib.stmpc_profile(self._h, 1, None))

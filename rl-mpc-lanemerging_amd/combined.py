@@ -51,10 +51,9 @@ def decide_batch(states, get_control, ctx=None):
     state the feasibility probe ran on).  ``get_control`` is called once per live state per rollout step,
     in state order, exactly as the reference calls its policy.
     """
-    if getattr(Settings, "TEST_ST_STRICTLY_BETTER", False) and st.finer_fit is None and \
-            Settings.TICK_LENGTH < Settings.T_DISCRETIZATION:
-        raise NotImplementedError("TEST_ST_STRICTLY_BETTER compares QP-resampled paths (st.finer_fit, SURVEY row f1), "
-                                  "which is not built; use the non-'b' combined configs")
+    if getattr(Settings, "TEST_ST_STRICTLY_BETTER", False):
+        raise NotImplementedError("the TEST_ST_STRICTLY_BETTER branch (dqn.py:156-197, the 'b' combined configs) is not built; "
+                                  "use the non-'b' combined configs")
     ctx = ctx or _capi.default_context()
     params = _capi.Params.from_settings(Settings)
     n = len(states)

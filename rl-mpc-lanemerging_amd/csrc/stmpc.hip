@@ -2,6 +2,7 @@
 // Host side: context, device buffers, launch sequencing on the caller's HIP stream.
 // No CPU fallback: every compute entry needs a HIP device.
 #include "stmpc_kernels.hpp"
+#include "stmpc_ff_kernels.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -68,6 +69,7 @@ struct stmpc_ctx {
     DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, proxy, order, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
+    DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
     bool stats_pending = false;
@@ -188,7 +190,8 @@ void stmpc_destroy(stmpc_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
-                     &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3};
+                     &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
+                     &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -701,3 +704,139 @@ int stmpc_probe_arith(stmpc_ctx *c, int op, const double *a, const double *b, do
 }
 
 }  // extern "C"
+
+namespace {
+int make_ffconst(const stmpc_params *p, double dt, double cdt, int maxiters, FFConst *k) {
+    if (!p) return fail(STMPC_EINVAL, "params is NULL");
+    if (!(dt > 0) || !(cdt > 0)) return fail(STMPC_EINVAL, "delta_t and coarse_delta_t must be positive");
+    if (maxiters < 0) return fail(STMPC_EINVAL, "maxiters must be >= 0");
+    memset(k, 0, sizeof *k);
+    const double dt2 = host_pow(dt, 2.0), dt3 = host_pow(dt, 3.0);   // delta_t ** 2, delta_t ** 3 (st.py:626,644)
+    k->dt = dt; k->cdt = cdt; k->dt2 = dt2;
+    k->cv = 1.0 / dt;                                                // st.py:613
+    k->ca1 = 1.0 / dt2; k->ca2 = 2.0 / dt2;                          // st.py:629-633
+    k->cj1 = 1.0 / dt3; k->cj2 = 2.0 / dt3; k->cj3 = 3.0 / dt3;      // st.py:646-658
+    k->v_max = p->v_max; k->a_max = p->a_max; k->a_min = p->a_min; k->j_max = p->j_max; k->j_min = p->j_min;
+    k->car_length = p->car_length;
+    k->maxiters = maxiters;
+    return STMPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int stmpc_finer_fit_batch(stmpc_ctx *c, const stmpc_params *p, double dt, double cdt, int maxiters, int N, int Hs,
+                          const double *s_seq, const int32_t *len, const double *v0, const double *a0, const double *bac,
+                          int n_max, double *out, int32_t *out_len, int32_t *iters) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Hs < 1 || Hs > 64 || n_max < 1) return fail(STMPC_EINVAL, "N, Hs (1..64) or n_max out of range");
+    if (N == 0) return STMPC_OK;
+    if (!s_seq || !len || !v0 || !a0 || !out || !out_len) return fail(STMPC_EINVAL, "NULL host pointer");
+    for (int i = 0; i < N; ++i) if (len[i] < 1 || len[i] > Hs) return fail(STMPC_EINVAL, "len[i] outside [1, Hs]");
+    FFArgs a;
+    memset(&a, 0, sizeof a);
+    int rc = make_ffconst(p, dt, cdt, maxiters, &a.k);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = c->f_seq.ensure((size_t)N * Hs * 8))) return rc;
+    if ((rc = c->f_len.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->f_v0.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->f_a0.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->f_out.ensure((size_t)N * n_max * 8))) return rc;
+    if ((rc = c->f_olen.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->f_iters.ensure((size_t)N * 4))) return rc;
+    HIPCHK(hipMemcpy(c->f_seq.p, s_seq, (size_t)N * Hs * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->f_len.p, len, (size_t)N * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->f_v0.p, v0, (size_t)N * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->f_a0.p, a0, (size_t)N * 8, hipMemcpyHostToDevice));
+    if (bac) {
+        if ((rc = c->f_bac.ensure((size_t)N * 32))) return rc;
+        HIPCHK(hipMemcpy(c->f_bac.p, bac, (size_t)N * 32, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemset(c->f_out.p, 0, (size_t)N * n_max * 8));
+    a.N = N; a.Hs = Hs; a.n_max = n_max; a.use_qp = 1;
+    a.s_seq = c->f_seq.as<double>(); a.len = c->f_len.as<int>(); a.v0 = c->f_v0.as<double>(); a.a0 = c->f_a0.as<double>();
+    a.bac = bac ? c->f_bac.as<double>() : nullptr;
+    a.out = c->f_out.as<double>(); a.out_len = c->f_olen.as<int>(); a.iters = c->f_iters.as<int>();
+    if (bac) hipLaunchKernelGGL(k_finer_fit<8>, dim3(N), dim3(64), 0, nullptr, a);
+    else hipLaunchKernelGGL(k_finer_fit<6>, dim3(N), dim3(64), 0, nullptr, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, c->f_out.p, (size_t)N * n_max * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_len, c->f_olen.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, c->f_iters.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    return STMPC_OK;
+}
+
+int stmpc_st_control_batch_device(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *d_ego,
+                                  const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
+                                  int32_t *d_bt, double *d_cost, double *d_speed, double *d_fine, int32_t *d_fine_len,
+                                  void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N == 0) return STMPC_OK;
+    if (!d_speed) return fail(STMPC_EINVAL, "NULL device pointer (speed)");
+    int rc = stmpc_solve_batch_device(c, p, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, nullptr, nullptr, stream);
+    if (rc) return rc;
+    FFArgs a;
+    memset(&a, 0, sizeof a);
+    const int H = stmpc_num_t(p);
+    double tv[STMPC_MAXH];
+    host_t_values(p, H, tv);
+    // finer_fit is called with (TICK_LENGTH, T_DISCRETIZATION) = the settings, not the arange spacing (st.py:771-772)
+    if ((rc = make_ffconst(p, tick, p->dt, STMPC_QP_MAXITERS, &a.k))) return rc;
+    a.N = N; a.Hs = H; a.n_max = STMPC_QP_NMAX; a.use_qp = (tick < p->dt) ? 1 : 0;
+    a.path_idx = d_path; a.best_t = d_bt; a.ego = d_ego; a.ds = p->ds;
+    a.out = d_fine; a.out_len = d_fine_len; a.speed = d_speed;
+    hipLaunchKernelGGL(k_finer_fit<6>, dim3(N), dim3(64), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_st_control_batch(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *ego,
+                           const int32_t *k, const double *ox, const double *ov, double *speed, int32_t *bt,
+                           int32_t *path, double *cost, double *fine, int32_t *fine_len) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N or Kmax out of range");
+    if (N == 0) return STMPC_OK;
+    if (!ego || !k || !speed || !bt) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (Kmax > 0 && (!ox || !ov)) return fail(STMPC_EINVAL, "NULL host pointer (other_x/other_v)");
+    for (int i = 0; i < N; ++i) if (k[i] < 0 || k[i] > Kmax) return fail(STMPC_EINVAL, "k_count[i] outside [0, Kmax]");
+    HIPCHK(hipSetDevice(c->device));
+    const int H = stmpc_num_t(p);
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "number of time layers must be in [2, 64]");
+    int rc;
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+    if ((rc = c->s_ego.ensure((size_t)N * 5 * 8))) return rc;
+    if ((rc = c->s_k.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->s_ox.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_ov.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->s_path.ensure((size_t)N * H * 4))) return rc;
+    if ((rc = c->s_bt.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->s_cost.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->f_speed.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->f_out.ensure((size_t)N * STMPC_QP_NMAX * 8))) return rc;
+    if ((rc = c->f_olen.ensure((size_t)N * 4))) return rc;
+    HIPCHK(hipMemcpy(c->s_ego.p, ego, (size_t)N * 5 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_k.p, k, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (Kmax > 0) {
+        HIPCHK(hipMemcpy(c->s_ox.p, ox, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->s_ov.p, ov, (size_t)N * Kmax * 8, hipMemcpyHostToDevice));
+    }
+    if (fine) HIPCHK(hipMemset(c->f_out.p, 0, (size_t)N * STMPC_QP_NMAX * 8));
+    rc = stmpc_st_control_batch_device(c, p, tick, N, Kmax, c->s_ego.as<double>(), c->s_k.as<int32_t>(), c->s_ox.as<double>(),
+                                       c->s_ov.as<double>(), c->s_path.as<int32_t>(), c->s_bt.as<int32_t>(), c->s_cost.as<double>(),
+                                       c->f_speed.as<double>(), c->f_out.as<double>(), c->f_olen.as<int>(), nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(speed, c->f_speed.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bt, c->s_bt.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (path) HIPCHK(hipMemcpy(path, c->s_path.p, (size_t)N * H * 4, hipMemcpyDeviceToHost));
+    if (cost) HIPCHK(hipMemcpy(cost, c->s_cost.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (fine) HIPCHK(hipMemcpy(fine, c->f_out.p, (size_t)N * STMPC_QP_NMAX * 8, hipMemcpyDeviceToHost));
+    if (fine_len) HIPCHK(hipMemcpy(fine_len, c->f_olen.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    stmpc_stats s;
+    return stmpc_get_stats(c, &s);
+}
+
+}  // extern "C"
+

@@ -9,6 +9,7 @@ Same names, argument meaning and failure conventions as the reference's ``st.py`
     find_s_t_obstacles_from_state(...)            <- st.find_s_t_obstacles_from_state   st.py:25
     get_appropriate_base_st_path_and_obstacles(s) <- same name                          st.py:726
     do_st_control(state)                          <- same name                          st.py:757
+    finer_fit(...)                                <- same name                          st.py:584
     test_guaranteed_crash_from_state(state)       <- same name                          st.py:790
     get_path_mean_abs_jerk(...)                   <- same name                          st.py:274
     get_range_index(...)                          <- same name                          st.py:20
@@ -116,43 +117,43 @@ def get_appropriate_base_st_path_and_obstacles(state):
     return seqs[0], obstacles, s_values, t_values, distances
 
 
-#: Optional QP smoother with the signature of the reference's ``st.finer_fit`` (st.py:584).  The
-#: reference applies it whenever TICK_LENGTH < T_DISCRETIZATION (st.py:770-772); it needs cvxopt and
-#: is SURVEY row f1 ("next").  While it is None, ``do_st_control`` commands the lattice's own
-#: first-step speed (s[1]-s[0]) / T_DISCRETIZATION instead of the QP-resampled one.
-finer_fit = None
+def finer_fit(s_sequence, delta_t, coarse_delta_t, start_speed, start_acceleration, before_after_cars=None):
+    """st.py:584-723: QP re-sampling of a coarse path to the simulator tick (one wavefront per QP on the GPU).
+
+    The reference solves the QP with ``cvxopt.solvers.qp`` (maxiters = 10, st.py:16-17); the kernel runs cvxopt's
+    published coneqp iteration with the same cap and tolerances (parity of the solve is unpinned: cvxopt is not
+    available to compare against).  At most 64 fine samples."""
+    s_sequence = np.ascontiguousarray(s_sequence, dtype=np.float64)
+    if len(s_sequence) == 1:                       # st.py:587-588
+        return s_sequence
+    params = _params_from_settings()
+    bac = None if before_after_cars is None else np.array([before_after_cars], dtype=np.float64)
+    out, out_len, _ = _capi.default_context().finer_fit_batch(
+        params, delta_t, coarse_delta_t, s_sequence[None, :], [len(s_sequence)], [start_speed], [start_acceleration], bac)
+    if out_len[0] < 0:
+        raise ValueError("finer_fit: more than %d fine samples are not supported" % _capi.QP_NMAX)
+    return out[0, :out_len[0]].copy()
 
 
 def do_st_control(state):
     """st.py:757-783.  Returns the commanded speed and forwards it to ``control.set_ego_speed``."""
-    ego_acceleration = state.ego_acceleration
-    ego_speed = state.ego_speed
-    seqs, _ = solve_states([state])
-    s_sequence = seqs[0]
+    ego, k_count, ox, ov = pack_states([state])
+    res = _capi.default_context().st_control_batch(_params_from_settings(), Settings.TICK_LENGTH, ego, k_count, ox, ov)
+    if res["best_t"][0] != _capi.num_t(_params_from_settings()) - 1:
+        print("ST Solver finds crash inevitable")              # st.py:765-766
+    speed = float(res["speed"][0])
+    control.set_ego_speed(speed)
+    return speed
 
-    end_point = len(s_sequence)
-    while s_sequence[end_point - 1] == 0:
-        end_point -= 1
-    if end_point != len(s_sequence):
-        print("ST Solver finds crash inevitable")
-    s_sequence = s_sequence[:end_point]
 
-    step_time = Settings.TICK_LENGTH
-    if Settings.TICK_LENGTH < Settings.T_DISCRETIZATION:
-        if finer_fit is not None:
-            s_sequence = finer_fit(s_sequence, Settings.TICK_LENGTH, Settings.T_DISCRETIZATION, ego_speed,
-                                   ego_acceleration)
-        else:
-            step_time = Settings.T_DISCRETIZATION
-
-    if len(s_sequence) <= 1:
-        control.set_ego_speed(ego_speed)
-        return ego_speed
-
-    planned_distance_first_step = s_sequence[1] - s_sequence[0]
-    end_speed_first_step = planned_distance_first_step / step_time
-    control.set_ego_speed(end_speed_first_step)
-    return end_speed_first_step
+def do_st_control_batch(states, params=None, ctx=None):
+    """``do_st_control`` for many independent states in one launch: returns ``(speeds[N], best_t[N])``.
+    No side effect on ``control`` (there is one ego per state; the caller forwards the speeds)."""
+    params = params or _params_from_settings()
+    ctx = ctx or _capi.default_context()
+    ego, k_count, ox, ov = pack_states(states)
+    res = ctx.st_control_batch(params, Settings.TICK_LENGTH, ego, k_count, ox, ov)
+    return res["speed"], res["best_t"]
 
 
 def test_guaranteed_crash_from_state(state):
