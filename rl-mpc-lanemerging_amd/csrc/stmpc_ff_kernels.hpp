@@ -8,7 +8,7 @@
 // three lane shuffles, the normal matrix P + G' D G has 7 diagonals, and its L D L' factor is a 64-step lane-serial
 // recurrence on v_readlane broadcasts.  The iteration is cvxopt's coneqp restricted to the componentwise cone
 // (Mehrotra predictor-corrector, same starting point, step rule, centering exponent, tolerances and iteration cap;
-// see oracle/ff_oracle.c for the restatement this kernel is checked against, bit for bit).
+// tests/test_finer_fit.py checks this kernel bit for bit against the CPU restatement of the same iteration).
 #pragma once
 #include <hip/hip_runtime.h>
 
