@@ -721,6 +721,25 @@ int make_ffconst(const stmpc_params *p, double dt, double cdt, int maxiters, FFC
     k->maxiters = maxiters;
     return STMPC_OK;
 }
+
+// Lanes per problem: the smallest of 16/32/64 that holds the longest fine grid a path of Hs samples can produce
+// (st.py:590-595); a wavefront then carries 64/GW problems.  The result bits do not depend on the choice.
+int ff_group_width(int Hs, double dt, double cdt) {
+    const double t_last = (double)(Hs - 1) * cdt;
+    int n = (int)rint(t_last / dt + 1.0);
+    if ((double)(n - 1) * dt > t_last) n -= 1;
+    if (Hs > 32 || n > 32) return 64;       // the coarse path itself is held one sample per lane
+    if (Hs > 16 || n > 16) return 32;
+    return 16;
+}
+
+void launch_finer_fit(const FFArgs &a, bool bounds, int gw, hipStream_t st) {
+    const dim3 block(64), grid((a.N + (64 / gw) - 1) / (64 / gw));
+#define STMPC_FF(NF_, GW_) hipLaunchKernelGGL((k_finer_fit<NF_, GW_>), grid, block, 0, st, a)
+    if (bounds) { if (gw == 16) STMPC_FF(8, 16); else if (gw == 32) STMPC_FF(8, 32); else STMPC_FF(8, 64); }
+    else { if (gw == 16) STMPC_FF(6, 16); else if (gw == 32) STMPC_FF(6, 32); else STMPC_FF(6, 64); }
+#undef STMPC_FF
+}
 }  // namespace
 
 extern "C" {
@@ -758,8 +777,7 @@ int stmpc_finer_fit_batch(stmpc_ctx *c, const stmpc_params *p, double dt, double
     a.s_seq = c->f_seq.as<double>(); a.len = c->f_len.as<int>(); a.v0 = c->f_v0.as<double>(); a.a0 = c->f_a0.as<double>();
     a.bac = bac ? c->f_bac.as<double>() : nullptr;
     a.out = c->f_out.as<double>(); a.out_len = c->f_olen.as<int>(); a.iters = c->f_iters.as<int>();
-    if (bac) hipLaunchKernelGGL(k_finer_fit<8>, dim3(N), dim3(64), 0, nullptr, a);
-    else hipLaunchKernelGGL(k_finer_fit<6>, dim3(N), dim3(64), 0, nullptr, a);
+    launch_finer_fit(a, bac != nullptr, ff_group_width(Hs, dt, cdt), nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, c->f_out.p, (size_t)N * n_max * 8, hipMemcpyDeviceToHost));
@@ -787,7 +805,7 @@ int stmpc_st_control_batch_device(stmpc_ctx *c, const stmpc_params *p, double ti
     a.N = N; a.Hs = H; a.n_max = STMPC_QP_NMAX; a.use_qp = (tick < p->dt) ? 1 : 0;
     a.path_idx = d_path; a.best_t = d_bt; a.ego = d_ego; a.ds = p->ds;
     a.out = d_fine; a.out_len = d_fine_len; a.speed = d_speed;
-    hipLaunchKernelGGL(k_finer_fit<6>, dim3(N), dim3(64), 0, (hipStream_t)stream, a);
+    launch_finer_fit(a, false, a.use_qp ? ff_group_width(H, tick, p->dt) : 64, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return STMPC_OK;
 }

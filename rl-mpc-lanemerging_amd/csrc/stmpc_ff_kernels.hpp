@@ -38,34 +38,53 @@ struct FFArgs {
     int use_qp;               // 0: TICK_LENGTH >= T_DISCRETIZATION, the coarse path is used as is (st.py:771)
     // outputs (any may be null)
     double *out;              // [N][n_max]
-    int *out_len;             // [N]; -1: more than 64 fine samples (not supported)
+    int *out_len;             // [N]; -1: more fine samples than the launch's group width (at most 64 are supported)
     int *iters;               // [N]; iterations, negated when the cap was hit without convergence
     double *speed;            // [N]  (x_1 - x_0) / dt, or the current speed when the path has one point (st.py:774-783)
 };
 
-__device__ __forceinline__ double ff_at(double v, int src) {       // value of lane src, 0 outside the wavefront
-    const double r = __shfl(v, src & 63, 64);
-    return (src >= 0 && src < 64) ? r : 0.0;
+// A problem with at most GW (16, 32 or 64) fine samples occupies an aligned group of GW lanes, so a wavefront carries
+// 64 / GW problems.  Lanes past a problem's last sample hold zeros, which makes the narrower xor butterflies below
+// produce the same bits as the 64-wide one: results do not depend on how problems are packed.
+template <int GW>
+__device__ __forceinline__ double ff_at(double v, int gbase, int idx) {   // value of the group's lane idx, 0 outside the group
+    const double r = __shfl(v, gbase + (idx & (GW - 1)), 64);
+    return (idx >= 0 && idx < GW) ? r : 0.0;
 }
-__device__ __forceinline__ double ff_wave_sum(double v) {          // xor butterfly: every lane ends with the same bits
+// Value of the group's lane i (i uniform across the wavefront).  A full-width group broadcasts through v_readlane
+// (no LDS round trip on the lane-serial recurrences; EXEC is ignored); packed groups need a different source lane per
+// group, where one ds_bpermute beats 2-4 readlanes plus selects (measured).
+template <int GW>
+__device__ __forceinline__ double ff_bcast(double v, int gbase, int i) {
+    if constexpr (GW == 64) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        return __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
+    } else {
+        return __shfl(v, gbase + i, 64);
+    }
+}
+template <int GW>
+__device__ __forceinline__ double ff_wave_sum(double v) {          // xor butterfly: every lane of the group ends with the same bits
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    for (int off = GW / 2; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
     return v;
 }
+template <int GW>
 __device__ __forceinline__ double ff_wave_max(double v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    for (int off = GW / 2; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
 }
 
-template <int NF>
+template <int NF, int GW>
 struct FFLane {
     double cV[4], cA[4], cJ[4];
     double l1, l2, l3, invd;
-    int lane, n;
+    int lane, n, gbase;            // lane = index inside the group
+    int nmax;                      // largest n among the wavefront's groups: a wave-uniform bound for the descending sweeps
 
     __device__ __forceinline__ void gx(double x, double &gV, double &gA, double &gJ) const {
-        const double xm2 = ff_at(x, lane - 2), xm1 = ff_at(x, lane - 1), xp1 = ff_at(x, lane + 1);
+        const double xm2 = ff_at<GW>(x, gbase, lane - 2), xm1 = ff_at<GW>(x, gbase, lane - 1), xp1 = ff_at<GW>(x, gbase, lane + 1);
         gV = ((cV[0] * xm2 + cV[1] * xm1) + cV[2] * x) + cV[3] * xp1;
         gA = ((cA[0] * xm2 + cA[1] * xm1) + cA[2] * x) + cA[3] * xp1;
         gJ = ((cJ[0] * xm2 + cJ[1] * xm1) + cJ[2] * x) + cJ[3] * xp1;
@@ -76,7 +95,7 @@ struct FFLane {
         double t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = (cV[k] * wV + cA[k] * wA) + cJ[k] * wJ;
-        const double a0 = ff_at(t[0], lane + 2), a1 = ff_at(t[1], lane + 1), a3 = ff_at(t[3], lane - 1);
+        const double a0 = ff_at<GW>(t[0], gbase, lane + 2), a1 = ff_at<GW>(t[1], gbase, lane + 1), a3 = ff_at<GW>(t[3], gbase, lane - 1);
         const double bnd = (NF == 8) ? (u[NF - 1] - u[NF - 2]) : 0.0;
         return (((a0 + a1) + t[2]) + a3) + bnd;
     }
@@ -90,20 +109,20 @@ struct FFLane {
             for (int l = 0; l <= k; ++l)
                 T[k][l] = (((DV * cV[k]) * cV[l]) + ((DA * cA[k]) * cA[l])) + ((DJ * cJ[k]) * cJ[l]);
         double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0;
-        S0 = S0 + ff_at(T[0][0], lane + 2); S0 = S0 + ff_at(T[1][1], lane + 1); S0 = S0 + T[2][2]; S0 = S0 + ff_at(T[3][3], lane - 1);
-        S1 = S1 + ff_at(T[1][0], lane + 1); S1 = S1 + T[2][1]; S1 = S1 + ff_at(T[3][2], lane - 1);
-        S2 = S2 + T[2][0]; S2 = S2 + ff_at(T[3][1], lane - 1);
-        S3 = S3 + ff_at(T[3][0], lane - 1);
+        S0 = S0 + ff_at<GW>(T[0][0], gbase, lane + 2); S0 = S0 + ff_at<GW>(T[1][1], gbase, lane + 1); S0 = S0 + T[2][2]; S0 = S0 + ff_at<GW>(T[3][3], gbase, lane - 1);
+        S1 = S1 + ff_at<GW>(T[1][0], gbase, lane + 1); S1 = S1 + T[2][1]; S1 = S1 + ff_at<GW>(T[3][2], gbase, lane - 1);
+        S2 = S2 + T[2][0]; S2 = S2 + ff_at<GW>(T[3][1], gbase, lane - 1);
+        S3 = S3 + ff_at<GW>(T[3][0], gbase, lane - 1);
         const double bd = (NF == 8) ? (D[NF - 2] + D[NF - 1]) : 0.0;
         S0 = (2.0 + S0) + bd;
         l1 = 0.0; l2 = 0.0; l3 = 0.0; invd = 0.5;         // lanes >= n: S = 2 I
         for (int i = 0; i < n; ++i) {
-            const double l1_m2 = (i >= 2) ? __shfl(l1, i - 2, 64) : 0.0;
-            const double l1_m1 = (i >= 1) ? __shfl(l1, i - 1, 64) : 0.0;
-            const double l2_m1 = (i >= 1) ? __shfl(l2, i - 1, 64) : 0.0;
-            const double id_m1 = (i >= 1) ? __shfl(invd, i - 1, 64) : 0.0;
-            const double id_m2 = (i >= 2) ? __shfl(invd, i - 2, 64) : 0.0;
-            const double id_m3 = (i >= 3) ? __shfl(invd, i - 3, 64) : 0.0;
+            const double l1_m2 = (i >= 2) ? ff_bcast<GW>(l1, gbase, i - 2) : 0.0;
+            const double l1_m1 = (i >= 1) ? ff_bcast<GW>(l1, gbase, i - 1) : 0.0;
+            const double l2_m1 = (i >= 1) ? ff_bcast<GW>(l2, gbase, i - 1) : 0.0;
+            const double id_m1 = (i >= 1) ? ff_bcast<GW>(invd, gbase, i - 1) : 0.0;
+            const double id_m2 = (i >= 2) ? ff_bcast<GW>(invd, gbase, i - 2) : 0.0;
+            const double id_m3 = (i >= 3) ? ff_bcast<GW>(invd, gbase, i - 3) : 0.0;
             const double e3 = S3;
             const double e2 = S2 - e3 * l1_m2;
             const double e1 = (S1 - e3 * l2_m1) - e2 * l1_m1;
@@ -112,23 +131,48 @@ struct FFLane {
             if (lane == i) { l1 = n1; l2 = n2; l3 = n3; invd = 1.0 / d; }
         }
     }
+    // S u = rhs for two right-hand sides in one pair of lane-serial sweeps (same arithmetic per right-hand side)
+    __device__ __forceinline__ void solve2(double rhsA, double rhsB, double &outA, double &outB) const {
+        double yA = 0.0, yB = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double a1 = (i >= 1) ? ff_bcast<GW>(yA, gbase, i - 1) : 0.0, b1 = (i >= 1) ? ff_bcast<GW>(yB, gbase, i - 1) : 0.0;
+            const double a2 = (i >= 2) ? ff_bcast<GW>(yA, gbase, i - 2) : 0.0, b2 = (i >= 2) ? ff_bcast<GW>(yB, gbase, i - 2) : 0.0;
+            const double a3 = (i >= 3) ? ff_bcast<GW>(yA, gbase, i - 3) : 0.0, b3 = (i >= 3) ? ff_bcast<GW>(yB, gbase, i - 3) : 0.0;
+            const double vA = ((rhsA - l1 * a1) - l2 * a2) - l3 * a3;
+            const double vB = ((rhsB - l1 * b1) - l2 * b2) - l3 * b3;
+            if (lane == i) { yA = vA; yB = vB; }
+        }
+        yA = yA * invd; yB = yB * invd;
+        if (lane >= n) { yA = 0.0; yB = 0.0; }
+        const double u1 = ff_at<GW>(l1, gbase, lane + 1), u2 = ff_at<GW>(l2, gbase, lane + 2), u3 = ff_at<GW>(l3, gbase, lane + 3);
+        double uA = 0.0, uB = 0.0;
+        for (int i = nmax - 1; i >= 0; --i) {      // uniform i (v_readlane needs it); rows i >= n stay 0
+            const double a1 = (i + 1 < GW) ? ff_bcast<GW>(uA, gbase, i + 1) : 0.0, b1 = (i + 1 < GW) ? ff_bcast<GW>(uB, gbase, i + 1) : 0.0;
+            const double a2 = (i + 2 < GW) ? ff_bcast<GW>(uA, gbase, i + 2) : 0.0, b2 = (i + 2 < GW) ? ff_bcast<GW>(uB, gbase, i + 2) : 0.0;
+            const double a3 = (i + 3 < GW) ? ff_bcast<GW>(uA, gbase, i + 3) : 0.0, b3 = (i + 3 < GW) ? ff_bcast<GW>(uB, gbase, i + 3) : 0.0;
+            const double vA = ((yA - u1 * a1) - u2 * a2) - u3 * a3;
+            const double vB = ((yB - u1 * b1) - u2 * b2) - u3 * b3;
+            if (lane == i) { uA = vA; uB = vB; }
+        }
+        outA = uA; outB = uB;
+    }
     __device__ __forceinline__ double solve(double rhs) const {
         double y = 0.0;
         for (int i = 0; i < n; ++i) {
-            const double y1 = (i >= 1) ? __shfl(y, i - 1, 64) : 0.0;
-            const double y2 = (i >= 2) ? __shfl(y, i - 2, 64) : 0.0;
-            const double y3 = (i >= 3) ? __shfl(y, i - 3, 64) : 0.0;
+            const double y1 = (i >= 1) ? ff_bcast<GW>(y, gbase, i - 1) : 0.0;
+            const double y2 = (i >= 2) ? ff_bcast<GW>(y, gbase, i - 2) : 0.0;
+            const double y3 = (i >= 3) ? ff_bcast<GW>(y, gbase, i - 3) : 0.0;
             const double v = ((rhs - l1 * y1) - l2 * y2) - l3 * y3;
             if (lane == i) y = v;
         }
         y = y * invd;
         if (lane >= n) y = 0.0;
-        const double u1 = ff_at(l1, lane + 1), u2 = ff_at(l2, lane + 2), u3 = ff_at(l3, lane + 3);
+        const double u1 = ff_at<GW>(l1, gbase, lane + 1), u2 = ff_at<GW>(l2, gbase, lane + 2), u3 = ff_at<GW>(l3, gbase, lane + 3);
         double u = 0.0;
-        for (int i = n - 1; i >= 0; --i) {
-            const double x1 = (i + 1 < 64) ? __shfl(u, (i + 1) & 63, 64) : 0.0;
-            const double x2 = (i + 2 < 64) ? __shfl(u, (i + 2) & 63, 64) : 0.0;
-            const double x3 = (i + 3 < 64) ? __shfl(u, (i + 3) & 63, 64) : 0.0;
+        for (int i = nmax - 1; i >= 0; --i) {
+            const double x1 = (i + 1 < GW) ? ff_bcast<GW>(u, gbase, i + 1) : 0.0;
+            const double x2 = (i + 2 < GW) ? ff_bcast<GW>(u, gbase, i + 2) : 0.0;
+            const double x3 = (i + 3 < GW) ? ff_bcast<GW>(u, gbase, i + 3) : 0.0;
             const double v = ((y - u1 * x1) - u2 * x2) - u3 * x3;
             if (lane == i) u = v;
         }
@@ -137,7 +181,7 @@ struct FFLane {
 };
 
 // numpy.interp on the coarse path held one sample per lane (scipy interp1d linear delegates to it), st.py:597-598
-__device__ __forceinline__ double ff_interp_lane(double sc, int len, double cdt, double x) {
+__device__ __forceinline__ double ff_interp_lane(double sc, int gbase, int len, double cdt, double x) {
     const double t_last = (double)(len - 1) * cdt;
     int j = (int)(x / cdt);
     j = j < 0 ? 0 : (j > len - 2 ? len - 2 : j);
@@ -145,7 +189,7 @@ __device__ __forceinline__ double ff_interp_lane(double sc, int len, double cdt,
     for (int it = 0; it < 2; ++it) { if (j + 1 <= len - 2 && (double)(j + 1) * cdt <= x) ++j; }
 #pragma unroll
     for (int it = 0; it < 2; ++it) { if (j > 0 && (double)j * cdt > x) --j; }
-    const double f0 = __shfl(sc, j, 64), f1 = __shfl(sc, j + 1, 64), fl = __shfl(sc, len - 1, 64);
+    const double f0 = __shfl(sc, gbase + j, 64), f1 = __shfl(sc, gbase + j + 1, 64), fl = __shfl(sc, gbase + len - 1, 64);
     const double t0 = (double)j * cdt, t1 = (double)(j + 1) * cdt;
     if (x >= t_last) return fl;
     if (t0 == x) return f0;
@@ -153,9 +197,10 @@ __device__ __forceinline__ double ff_interp_lane(double sc, int len, double cdt,
     return slope * (x - t0) + f0;
 }
 
-template <int NF>
+template <int NF, int GW>
 __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x & (GW - 1), gbase = threadIdx.x - lane;     // lane: index inside the problem's group
+    const int e = blockIdx.x * (64 / GW) + threadIdx.x / GW;
     if (e >= a.N) return;
     const FFConst &k = a.k;
     // ---- coarse path, one sample per lane
@@ -172,7 +217,7 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
         if (lane < len) sc = a.s_seq[(size_t)e * a.Hs + lane];
         v0 = a.v0[e]; a0 = a.a0[e];
     }
-    const double s_first = __shfl(sc, 0, 64), s_second = __shfl(sc, 1, 64);   // shuffles stay outside divergent code
+    const double s_first = __shfl(sc, gbase, 64), s_second = __shfl(sc, gbase + 1, 64);   // shuffles stay outside divergent code
     if (len <= 1 || !a.use_qp) {                                      // st.py:587-588 / st.py:771, then st.py:774-783
         if (a.out && lane < len && lane < a.n_max) a.out[(size_t)e * a.n_max + lane] = sc;
         if (lane == 0) {
@@ -186,17 +231,23 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     const double t_last = (double)(len - 1) * k.cdt;
     int n = (int)rint(t_last / k.dt + 1.0);
     if ((double)(n - 1) * k.dt > t_last) n -= 1;
-    if (n < 2 || n > 64) {
+    if (n < 2 || n > GW) {
         if (lane == 0) { if (a.out_len) a.out_len[e] = -1; if (a.iters) a.iters[e] = 0; if (a.speed) a.speed[e] = __builtin_nan(""); }
         return;
     }
-    const double bi_all = ff_interp_lane(sc, len, k.cdt, (double)lane * k.dt);   // all lanes: the shuffles inside need them
+    const double bi_all = ff_interp_lane(sc, gbase, len, k.cdt, (double)lane * k.dt);   // all lanes: the shuffles inside need them
     const double bi = (lane < n) ? bi_all : 0.0;
     const double qv = -2.0 * bi;
     const double beq = s_first;
 
-    FFLane<NF> L;
-    L.lane = lane; L.n = n;
+    FFLane<NF, GW> L;
+    L.lane = lane; L.n = n; L.gbase = gbase;
+    {
+        int nm = n;
+#pragma unroll
+        for (int off = 32; off >= GW; off >>= 1) { const int o = __shfl_xor(nm, off, 64); nm = (o > nm && o <= GW) ? o : nm; }
+        L.nmax = __builtin_amdgcn_readfirstlane(nm);
+    }
     const int r = lane;
     const bool row = r < n - 1;
 #pragma unroll
@@ -233,15 +284,15 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     for (int f = 0; f < NF; ++f) { if (!act[f]) h[f] = 0.0; mloc += act[f] ? 1 : 0; }
     int m = mloc;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m += __shfl_xor(m, off, 64);
+    for (int off = GW / 2; off >= 1; off >>= 1) m += __shfl_xor(m, off, 64);
 
     const double STEP = 0.99, ABSTOL = 1e-7, RELTOL = 1e-6, FEASTOL = 1e-7;   // cvxopt defaults
-    double resx0 = sqrt(ff_wave_sum(qv * qv)); resx0 = resx0 > 1.0 ? resx0 : 1.0;
+    double resx0 = sqrt(ff_wave_sum<GW>(qv * qv)); resx0 = resx0 > 1.0 ? resx0 : 1.0;
     const double resy0 = fabs(beq) > 1.0 ? fabs(beq) : 1.0;
     double hh = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) hh = hh + h[f] * h[f];
-    double resz0 = sqrt(ff_wave_sum(hh)); resz0 = resz0 > 1.0 ? resz0 : 1.0;
+    double resz0 = sqrt(ff_wave_sum<GW>(hh)); resz0 = resz0 > 1.0 ? resz0 : 1.0;
     const double e0 = (lane == 0) ? 1.0 : 0.0;
 
     // ---- starting point: [P A' G'; A 0 0; G 0 -I] [x; y; z] = [-q; b; h], s = -z, shifted into the cone
@@ -251,9 +302,9 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     L.factor(D);
     double tmp = L.gt(uu);
     tmp = (lane < n) ? (-qv + tmp) : 0.0;
-    double u = L.solve(tmp);
-    double v = L.solve(e0);
-    double y = (__shfl(u, 0, 64) - beq) / __shfl(v, 0, 64);
+    double u, v;
+    L.solve2(tmp, e0, u, v);
+    double y = (__shfl(u, gbase, 64) - beq) / __shfl(v, gbase, 64);
     double x = (lane < n) ? u - v * y : 0.0;
     {
         double gV, gA, gJ;
@@ -270,8 +321,8 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
                 ms = -s[f] > ms ? -s[f] : ms; mz = -z[f] > mz ? -z[f] : mz;
             } else { s[f] = 1.0; z[f] = 0.0; }
         }
-        const double nrm = sqrt(ff_wave_sum(nn));
-        const double ts = ff_wave_max(ms), tz = ff_wave_max(mz);
+        const double nrm = sqrt(ff_wave_sum<GW>(nn));
+        const double ts = ff_wave_max<GW>(ms), tz = ff_wave_max<GW>(mz);
         const double thr = -1e-8 * (nrm > 1.0 ? nrm : 1.0);
 #pragma unroll
         for (int f = 0; f < NF; ++f) if (act[f]) {
@@ -282,7 +333,7 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     double gp = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) if (act[f]) gp = gp + s[f] * z[f];
-    double gap = ff_wave_sum(gp);
+    double gap = ff_wave_sum<GW>(gp);
 
     int iters = 0;
     bool converged = false;
@@ -295,9 +346,9 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
         const double px = 2.0 * x + qv;
         const double f0p = x * px + x * qv;
         const double rx = (lane < n) ? (px + (lane == 0 ? y : 0.0)) + tmp : 0.0;
-        const double f0 = 0.5 * ff_wave_sum(f0p);
-        const double resx = sqrt(ff_wave_sum(rx * rx));
-        const double ry = __shfl(x, 0, 64) - beq;
+        const double f0 = 0.5 * ff_wave_sum<GW>(f0p);
+        const double resx = sqrt(ff_wave_sum<GW>(rx * rx));
+        const double ry = __shfl(x, gbase, 64) - beq;
         const double resy = fabs(ry);
         double rzn = 0.0, rzz = 0.0;
         {
@@ -313,8 +364,8 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
                 rzz = rzz + (act[f] ? z[f] * rz[f] : 0.0);
             }
         }
-        const double resz = sqrt(ff_wave_sum(rzn));
-        const double pcost = f0, dcost = ((f0 + y * ry) + ff_wave_sum(rzz)) - gap;
+        const double resz = sqrt(ff_wave_sum<GW>(rzn));
+        const double pcost = f0, dcost = ((f0 + y * ry) + ff_wave_sum<GW>(rzz)) - gap;
         bool have_rel = false;
         double relgap = 0.0;
         if (pcost < 0.0) { relgap = gap / -pcost; have_rel = true; }
@@ -327,8 +378,7 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) D[f] = act[f] ? z[f] / s[f] : 0.0;
         L.factor(D);
-        v = L.solve(e0);
-        const double v_0 = __shfl(v, 0, 64);
+        double v_0 = 0.0;
         const double mu = gap / (double)m;
         double sigma = 0.0, step = 1.0, dx = 0.0, dy = 0.0;
         double ds[NF], dz[NF], dsdz_a[NF];
@@ -343,8 +393,9 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
             }
             tmp = L.gt(uu);
             tmp = (lane < n) ? -rx - tmp : 0.0;
-            u = L.solve(tmp);
-            dy = (__shfl(u, 0, 64) + ry) / v_0;
+            if (pass == 0) { L.solve2(tmp, e0, u, v); v_0 = __shfl(v, gbase, 64); }     // v = S^-1 A' rides along with the predictor
+            else u = L.solve(tmp);
+            dy = (__shfl(u, gbase, 64) + ry) / v_0;
             dx = (lane < n) ? u - v * dy : 0.0;
             double gV, gA, gJ;
             L.gx(dx, gV, gA, gJ);
@@ -361,9 +412,9 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
                 const double qs = -ds[f] / s[f], qz = -dz[f] / z[f];
                 ms = qs > ms ? qs : ms; mz = qz > mz ? qz : mz;
             }
-            const double dsdz = ff_wave_sum(pd);
-            double t = ff_wave_max(ms);
-            const double tz = ff_wave_max(mz);
+            const double dsdz = ff_wave_sum<GW>(pd);
+            double t = ff_wave_max<GW>(ms);
+            const double tz = ff_wave_max<GW>(mz);
             t = t > tz ? t : tz; t = t > 0.0 ? t : 0.0;
             if (t == 0.0) step = 1.0;
             else if (pass == 0) step = 1.0 / t < 1.0 ? 1.0 / t : 1.0;
@@ -385,10 +436,10 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
             z[f] = z[f] + step * dz[f];
             gp = gp + s[f] * z[f];
         }
-        gap = ff_wave_sum(gp);
+        gap = ff_wave_sum<GW>(gp);
     }
     if (a.out && lane < n && lane < a.n_max) a.out[(size_t)e * a.n_max + lane] = x;
-    const double x1 = __shfl(x, 1, 64), x0 = __shfl(x, 0, 64);
+    const double x1 = __shfl(x, gbase + 1, 64), x0 = __shfl(x, gbase, 64);
     if (lane == 0) {
         if (a.out_len) a.out_len[e] = n;
         if (a.iters) a.iters[e] = converged ? iters : -iters;
