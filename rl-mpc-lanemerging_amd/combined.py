@@ -32,9 +32,9 @@ def get_ego_speed_from_jerk(current_speed, current_acceleration, jerk):
     return new_speed
 
 
-REASON_RL, REASON_CRASH, REASON_SPEED, REASON_ROLLOUT = 0, 1, 2, 3
+REASON_RL, REASON_CRASH, REASON_SPEED, REASON_ROLLOUT, REASON_ST_BETTER = 0, 1, 2, 3, 4
 REASON_NAMES = {REASON_RL: "rl", REASON_CRASH: "crash predicted", REASON_SPEED: "too fast",
-                REASON_ROLLOUT: "st solver not happy with rollout state"}
+                REASON_ROLLOUT: "st solver not happy with rollout state", REASON_ST_BETTER: "st path deemed better"}
 
 
 def _unpack(ego4, k, ox, ov, i):
@@ -43,17 +43,17 @@ def _unpack(ego4, k, ox, ov, i):
                         [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [0.0] * kk)
 
 
-def decide_batch(states, get_control, ctx=None):
+def decide_batch(states, get_control, ctx=None, last_choice_rl=None):
     """Decision part of ``do_combined_control`` for a list of states.
 
     Returns a dict: ``takeover[n]`` (bool), ``reason[n]`` (REASON_*), ``first_action[n]``, ``selected_speed[n]``
     (speed of the last rollout step), ``crash_predicted[n]``, ``test_states`` (list of HighwayState, the
-    state the feasibility probe ran on).  ``get_control`` is called once per live state per rollout step,
-    in state order, exactly as the reference calls its policy.
+    state the feasibility probe ran on), ``st_speed[n]`` (NaN unless the ST path was chosen by the
+    strictly-better comparison, dqn.py:156-197; then the speed to command).  ``get_control`` is called once per
+    live state per rollout step, in state order, exactly as the reference calls its policy.
+    ``last_choice_rl[n]``: whether the previous tick of that episode was left to the policy (dqn.py:124-126;
+    default True = empty takeover history).
     """
-    if getattr(Settings, "TEST_ST_STRICTLY_BETTER", False):
-        raise NotImplementedError("the TEST_ST_STRICTLY_BETTER branch (dqn.py:156-197, the 'b' combined configs) is not built; "
-                                  "use the non-'b' combined configs")
     ctx = ctx or _capi.default_context()
     params = _capi.Params.from_settings(Settings)
     n = len(states)
@@ -63,6 +63,7 @@ def decide_batch(states, get_control, ctx=None):
     crash_predicted = np.zeros(n, dtype=bool)
     selected_speed = np.zeros(n, dtype=np.float64)
     live = np.ones(n, dtype=bool)
+    rollout_s = [[float(ego5[j, 4])] for j in range(n)]                            # dqn.py:121
     test_ego = ego4.copy(); test_ox = ox.copy(); test_ov = ov.copy(); have_test = np.zeros(n, dtype=bool)
     cur_ego, cur_ox, cur_ov = ego4.copy(), ox.copy(), ov.copy()
     steps = max(Settings.ROLLOUT_LENGTH, 1)
@@ -84,6 +85,8 @@ def decide_batch(states, get_control, ctx=None):
         if i == Settings.ST_TEST_ROLLOUTS:
             test_ego[idx], test_ox[idx], test_ov[idx] = eo, xo, vo
             have_test[idx] = True
+        for r, j in enumerate(idx):                                                # dqn.py:138
+            rollout_s[j].append(control.get_ego_s((float(eo[r, 0]), float(eo[r, 1]))))
         live[idx] = ~crash_predicted[idx] & ~(eo[:, 0] > Settings.STOP_X)
     nt = ~have_test                                                               # dqn.py:142-143
     test_ego[nt], test_ox[nt], test_ov[nt] = cur_ego[nt], cur_ox[nt], cur_ov[nt]
@@ -100,8 +103,36 @@ def decide_batch(states, get_control, ctx=None):
         if idx.size:
             _, res = st.solve_states([test_states[j] for j in idx], ctx=ctx)       # one batched probe (dqn.py:152)
             reason[idx[res["crash"].astype(bool)]] = REASON_ROLLOUT
+    st_speed = np.full(n, np.nan)
+    if getattr(Settings, "TEST_ST_STRICTLY_BETTER", False):                        # dqn.py:156-197
+        idx = np.nonzero(reason == REASON_RL)[0]
+        if idx.size:
+            last_rl = np.ones(n, dtype=bool) if last_choice_rl is None else np.asarray(last_choice_rl, dtype=bool)
+            res = ctx.st_control_batch(params, Settings.TICK_LENGTH, ego5[idx], k[idx], ox[idx], ov[idx], want_paths=True)
+            for r, j in enumerate(idx):
+                m = int(res["fine_len"][r])
+                if m < 0:
+                    raise ValueError("finer_fit: more than %d fine samples are not supported" % _capi.QP_NMAX)
+                s_seq = res["fine"][r, :m]                                          # trimmed, QP-resampled when TICK < T_DISCRETIZATION
+                if m <= 1:                                                         # dqn.py:167-169
+                    continue
+                hist = rollout_s[j]
+                ml = min(m, len(hist))
+                v0, a0 = float(ego5[j, 2]), float(ego5[j, 3])
+                st_jerk = st.get_path_mean_abs_jerk(s_seq[:ml], v0, a0, Settings.TICK_LENGTH)
+                rl_jerk = st.get_path_mean_abs_jerk(hist[:ml], v0, a0, Settings.TICK_LENGTH)
+                st_distance = s_seq[ml - 1] - s_seq[0]
+                rl_distance = hist[ml - 1] - hist[0]
+                if last_rl[j] or not Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED:
+                    choose_st = (st_jerk < rl_jerk and st_distance > rl_distance) or rl_distance == 0
+                else:
+                    choose_st = not (rl_jerk < st_jerk and rl_distance > st_distance)
+                if choose_st:
+                    reason[j] = REASON_ST_BETTER
+                    st_speed[j] = (s_seq[1] - s_seq[0]) / Settings.TICK_LENGTH     # dqn.py:180-181,192-193
     return {"takeover": reason != REASON_RL, "reason": reason, "first_action": first_action,
-            "selected_speed": selected_speed, "crash_predicted": crash_predicted, "test_states": test_states}
+            "selected_speed": selected_speed, "crash_predicted": crash_predicted, "test_states": test_states,
+            "st_speed": st_speed, "rollout_s": rollout_s}
 
 
 class CombinedController:
@@ -112,9 +143,16 @@ class CombinedController:
         self.takeover_history = []
 
     def do_combined_control(self, state):
-        d = decide_batch([state], self.get_control)
+        last_choice_rl = not (len(self.takeover_history) > 0 and self.takeover_history[-1])     # dqn.py:124-126
+        d = decide_batch([state], self.get_control, last_choice_rl=[last_choice_rl])
         take = bool(d["takeover"][0])
         self.takeover_history.append(take)
+        if int(d["reason"][0]) == REASON_ST_BETTER:
+            if last_choice_rl or not Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED:
+                print("ST Path deemed better")
+            speed = float(d["st_speed"][0])
+            control.set_ego_speed(speed)
+            return speed
         if take:
             print({REASON_CRASH: "Crash predicted", REASON_SPEED: "DDPG going too fast",
                    REASON_ROLLOUT: "ST solver not happy with rollout state"}[int(d["reason"][0])])

@@ -46,11 +46,13 @@ class Settings:
     # Combined controller (config.py:146-155)
     ROLLOUT_LENGTH = 5
     ST_TEST_ROLLOUTS = 5
+    LIMIT_DQN_SPEED = False
     TEST_ST_STRICTLY_BETTER = True
     TEST_ROLLOUT_STATE = True
     CHECK_ROLLOUT_CRASH = True
     COMBINATION_MIN_DISTANCE = 5.1
     STOP_X = 65
+    REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED = False
 
     @classmethod
     def export_settings(cls):

@@ -5,6 +5,12 @@ dqn.py:117-200), generated from the reference itself with a deterministic stand-
 Build-container only (needs /root/reference).  Inert stand-ins: traci, cvxopt and torch.utils.tensorboard
 (logging) -- none is called on this path.  st.do_st_control and control.set_ego_jerk (TraCI side effects) are
 replaced by recorders so that only the DECISION is captured; the QP-resampled speed is not (cvxopt absent).
+
+Second part ("b_*" arrays): the TEST_ST_STRICTLY_BETTER branch (dqn.py:156-197, the 'b' configs), which compares the
+QP-resampled ST path with the policy's rollout.  The reference's own lattice solver, rollout, jerk/distance
+comparison and switching rules run unmodified; only `st.finer_fit`'s call into cvxopt is replaced -- by this repo's
+restatement of cvxopt's iteration (oracle/ff_oracle.c), since cvxopt is not installed.  These vectors therefore pin
+the branch's logic around the QP, not the QP solve itself.
 """
 import os
 import sys
@@ -85,6 +91,51 @@ def main():
                         flags=np.array([int(S.CHECK_ROLLOUT_CRASH), int(S.LIMIT_DQN_SPEED), int(S.TEST_ROLLOUT_STATE),
                                         int(S.TEST_ST_STRICTLY_BETTER)]))
     print("combined: %d states, %d takeovers, reasons %s" % (len(k), int(takeover.sum()), np.bincount(reason).tolist()))
+
+    # ---- part b: TEST_ST_STRICTLY_BETTER
+    from oracle import ff_oracle as ff
+    FS = ff.settings(S.MAX_SPEED, S.MAX_POSITIVE_ACCELERATION, S.MAX_NEGATIVE_ACCELERATION, S.MAXIMUM_POSITIVE_JERK,
+                     S.MINIMUM_NEGATIVE_JERK, S.CAR_LENGTH)
+
+    def finer_fit(s_sequence, delta_t, coarse_delta_t, start_speed, start_acceleration, before_after_cars=None):
+        return ff.finer_fit(np.asarray(s_sequence, dtype=np.float64), delta_t, coarse_delta_t, start_speed, start_acceleration, FS,
+                            before_after_cars)[0]
+    st.finer_fit = finer_fit
+    S.TEST_ST_STRICTLY_BETTER = True
+    nb = 360
+    b_takeover = np.zeros(nb, dtype=np.int32); b_reason = np.zeros(nb, dtype=np.int32)
+    b_speed = np.full(nb, np.nan); b_last_rl = np.ones(nb, dtype=np.int32); b_remember = np.zeros(nb, dtype=np.int32)
+    codes["ST Path deemed better"] = 4
+    codes["RL path deemed better"] = 0
+    sent = []
+    control.set_ego_speed = lambda v: sent.append(float(v))
+    for i in range(nb):
+        kk = int(k[i])
+        state = prediction.HighwayState((float(ego[i, 0]), float(ego[i, 1])), float(ego[i, 2]), float(ego[i, 3]),
+                                        [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [0.0] * kk)
+        agent = Agent()
+        b_remember[i] = int(i >= nb // 2)
+        S.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED = bool(b_remember[i])
+        if i % 3 == 1:
+            agent.takeover_history.append(True)                 # previous tick was an ST takeover
+            b_last_rl[i] = 0
+        calls.clear(); msgs.clear(); sent.clear()
+        agent.do_combined_control(state)
+        b_takeover[i] = int(agent.takeover_history[-1])
+        if "st" in calls:                                        # crash / rollout-probe takeovers: do_st_control(start_state)
+            b_reason[i] = codes[msgs[0]]
+        elif sent:                                               # ST path chosen by the comparison
+            b_reason[i] = 4
+            b_speed[i] = sent[0]
+        else:
+            b_reason[i] = 0
+        assert b_takeover[i] == int(b_reason[i] != 0)
+    S.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED = False
+    S.TEST_ST_STRICTLY_BETTER = False
+    np.savez_compressed(os.path.join(HERE, "golden_combined_b.npz"), n=np.array(nb), b_takeover=b_takeover, b_reason=b_reason,
+                        b_speed=b_speed, b_last_rl=b_last_rl, b_remember=b_remember)
+    print("combined b: %d states, reasons %s (remember off) %s (remember on)" % (
+        nb, np.bincount(b_reason[:nb // 2], minlength=5).tolist(), np.bincount(b_reason[nb // 2:], minlength=5).tolist()))
 
 
 if __name__ == "__main__":
