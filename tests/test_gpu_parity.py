@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C-ABI) against the golden vectors of the
 reference and against the CPU oracle on seeded inputs.  Bit-exact on every integer output
 and on the fp64 cost (the north_star tolerance is 1e-6 relative; we assert equality)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -285,3 +287,41 @@ def test_full_size_batch_properties(gpu_ctx, restore_settings):
     sel = np.arange(0, n, 64)
     ref = orc.solve_batch(op, ego[sel], kc[sel], ox[sel], ov[sel], solver="heap", nthreads=8)
     assert np.array_equal(ref["path_idx"], path[sel]) and np.array_equal(ref["cost"], r1["cost"][sel])
+
+
+def _random_overrides(rng):
+    ds = float(rng.choice([0.025, 0.05, 0.1, 0.2]))
+    dt = float(rng.choice([0.2, 0.25, 0.3, 0.4, 0.5]))
+    H = int(rng.integers(3, 41))
+    over = dict(S_DISCRETIZATION=ds, T_DISCRETIZATION=dt, FUTURE_T=round((H - 1) * dt, 6),
+                FUTURE_S=float(rng.choice([40.0, 80.0, 150.0, 300.0])) * (1.0 if ds >= 0.05 else 0.5),
+                V_WEIGHT=float(rng.choice([0.0, 0.5, 3.0, 10.0])), A_WEIGHT=float(rng.choice([0.0, 1.0, 10.0])),
+                J_WEIGHT=float(rng.choice([0.0, 1.0, 10.0])), D_WEIGHT=float(rng.choice([0.0, 1.0, 10.0])),
+                DESIRED_SPEED=float(rng.uniform(5.0, 25.0)), MAX_SPEED=float(rng.uniform(20.0, 35.0)),
+                MAX_POSITIVE_ACCELERATION=float(rng.uniform(1.0, 6.0)), MAX_NEGATIVE_ACCELERATION=-float(rng.uniform(2.0, 8.0)),
+                MAXIMUM_POSITIVE_JERK=float(rng.choice([2.0, 10.0, 35.0])), MINIMUM_NEGATIVE_JERK=-float(rng.choice([2.0, 10.0, 35.0])),
+                MIN_ALLOWED_DISTANCE=float(rng.choice([0.0, 2.0, 5.0, 8.0])), CRASH_MIN_S=float(rng.uniform(6.0, 25.0)),
+                START_UNCERTAINTY=float(rng.choice([0.0, 0.0, 0.5])), UNCERTAINTY_PER_SECOND=float(rng.choice([0.0, 0.0, 0.3])),
+                MAX_PREDICTED_DECELERATION=-float(rng.uniform(1.0, 6.0)))
+    return over
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("STMPC_FUZZ_SEEDS", "16")))))
+def test_random_parameter_sets_match_oracle(seed, gpu_ctx, restore_settings):
+    """Seeded random Settings (lattice spacing, horizon, weights incl. zeros, binding and non-binding limits,
+    uncertainty growth): every kernel variant and window tier the parameters select must reproduce the oracle."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    rng = np.random.default_rng(9000 + seed)
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(_random_overrides(rng))
+    p = _capi.Params.from_settings(pkg.Settings)
+    H, S = _capi.num_t(p), _capi.num_s(p, 0.0)
+    assert 2 <= H <= 64 and 2 <= S <= 65000
+    op = orc.OrcParams.from_dict(p.as_dict())
+    kmax = int(rng.choice([4, 8, 12]))
+    ego, kc, ox, ov = synth.generate_states(160, k=int(rng.integers(0, kmax + 1)), kmax=kmax, seed=500 + seed, vary_k=True, dt=p.dt)
+    res = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=8)
+    _check(res, ref, H)
