@@ -947,12 +947,13 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
             int bn = out.nodes;
             if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
-            else {
+            else if (rc == 0) {
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
                 bn += out.nodes;
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
+            if (rc != 0 && !a.last_tier) return rc;
             if (a.phase == 1) {                               // bound-only phase: publish the bound and a work estimate
                 if (tid == 0) {
                     a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
@@ -1088,9 +1089,13 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
                     unsigned w = atomicAdd(&a.counters[a.phase == 1 ? 2 : 0], 1u);
                     if (w < (unsigned)a.N) e = a.order ? a.order[w] : (int)w;
                 } else {
+                    // the tier's queue: episodes without a cost bound (the expensive ones) from the front, the others
+                    // from the back of the same array; heaviest first keeps the tail of this launch short
                     unsigned w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
                     unsigned cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w < cnt) e = a.lists[(size_t)a.tier * a.N + w];
+                    unsigned heavy = __hip_atomic_load(&a.counters[4 * a.tier + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w < heavy) e = a.lists[(size_t)a.tier * a.N + w];
+                    else if (w < cnt) e = a.lists[(size_t)a.tier * a.N + (a.N - 1 - (w - heavy))];
                 }
                 sh.work = e;
             }
@@ -1100,8 +1105,11 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
             int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
-                    unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
-                    a.lists[(size_t)(a.tier + 1) * a.N + pos] = e;
+                    atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
+                    const u64 ub = a.ubound ? a.ubound[e] : 0ull;          // written by this thread in solve_episode
+                    const bool heavy = (ub == 0ull || ub == INF_BITS);
+                    const unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1) + (heavy ? 2 : 3)], 1u);
+                    a.lists[(size_t)(a.tier + 1) * a.N + (heavy ? pos : (unsigned)a.N - 1u - pos)] = e;
                 } else {
                     atomicExch(&a.counters[STMPC_CNT_ERR], 1u);   // the last tier's window covers all S cells
                 }
