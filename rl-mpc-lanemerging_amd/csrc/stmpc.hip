@@ -95,6 +95,10 @@ struct stmpc_ctx {
     bool allow_stage_tab = false;  // STMPC_STAGE_TAB=1: stage the vehicle table in LDS + scalar registers (costs the 4th workgroup per CU)
     int last_nt = 0;
     bool last_has_hbm = true;
+    // STMPC_OVERLAP=0/1: start the second LDS tier on its own stream while the first is still running (see k_solve)
+    int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" {
@@ -181,6 +185,13 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_TWO_PHASE")) c->two_phase = atoi(w) != 0;
     if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        stmpc_destroy(c);
+        return fail(STMPC_EHIP, "stream/event creation failed");
+    }
     *out = c;
     return STMPC_OK;
 }
@@ -193,6 +204,9 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -276,9 +290,9 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, u64 *ubound, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, hipStream_t st) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1);
 }
 
 }  // namespace
@@ -375,17 +389,23 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         e0 = c->pool[c->pool_used]; e1 = c->pool[c->pool_used + 1]; e2 = c->pool[c->pool_used + 2]; e3 = c->pool[c->pool_used + 3];
         c->pool_used += 4;
     }
+    const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
+    // second LDS tier started alongside the first (see k_solve): only where overflow is common enough to pay for the
+    // extra launch, and not with the two-phase schedule (its first launch of tier 0 only bounds)
+    const bool overlap = nt >= 2 && tierLds[1] && !(prune_on && c->two_phase) && N > tierGrid[0] &&
+                         (c->overlap < 0 ? prune_on != 0 : c->overlap != 0);
+    int *queue1 = overlap ? c->lists.as<int>() + (size_t)N : nullptr;
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
     a.p = dp; a.N = N; a.Kmax = Kalloc;
     a.ego = d_ego; a.tab = tab;
     a.counters = counters; a.lists = c->lists.as<int>(); a.ubound = c->ubound.as<u64>();
-    a.prune = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
+    a.prune = prune_on;
     // band of the bounding pre-pass: half the per-step cost of standing still (225 with the reference's
     // weights; measured optimum of a 60..1200 sweep on the H=40 workload); any value is safe (the exact pass
     // re-checks), it only trades pre-pass work for tightness of the bound
@@ -397,11 +417,18 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
     HIPCHK(hipEventRecord(e1, st));
-    for (int k = (two_phase ? -1 : 0); k < nt; ++k) {
-        const bool bound_phase = (k < 0);
-        if (bound_phase) k = 0;
-        a.phase = bound_phase ? 1 : (two_phase ? 2 : 0);
-        a.order = (!bound_phase && two_phase && k == 0) ? c->order.as<int>() : nullptr;
+    if (overlap) HIPCHK(hipEventRecord(c->ev_fork, st));      // the vehicle table and the preset queue are ready
+
+    // one launch of tier k: phase 0 = bound + exact, 1 = bounding pre-passes only, 2 = exact with the stored bounds;
+    // side = on the side stream, consuming tier 0's overflow queue while tier 0 is still running
+    auto launch_tier = [&](int k, int phase, bool side) -> int {
+        hipStream_t lst = side ? c->aux_stream : st;
+        a.concurrent = side ? 1 : 0;
+        a.feeds_concurrent = (overlap && k == 0) ? 1 : 0;
+        a.prev_grid = side ? tierGrid[0] : 0;
+        a.wait_ticks = side ? 20000000ull : 0ull;             // 0.2 s of the 100 MHz clock
+        a.phase = phase;
+        a.order = (phase == 2 && k == 0) ? c->order.as<int>() : nullptr;
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
@@ -412,7 +439,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
             if (lds > 48 * 1024)                                                                              \
                 HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG>,                  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG>), grid, block, lds, st, a);                \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG>), grid, block, lds, lst, a);               \
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
@@ -424,13 +451,26 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
             if (fastdiv) STMPC_LAUNCH_FM(false, true, 0); else STMPC_LAUNCH_FM(false, false, 0);
         }
 #undef STMPC_LAUNCH_FM
-        if (bound_phase) {
-            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, N, (const unsigned *)c->proxy.as<unsigned>(), c->order.as<int>());
-            k = -1;      // next iteration: tier 0 of the exact phase
-            continue;
-        }
 #undef STMPC_LAUNCH
 #undef STMPC_LAUNCH_S
+        return STMPC_OK;
+    };
+
+    if (two_phase) {                                           // bound every episode, order them heaviest-first
+        if ((rc = launch_tier(0, 1, false))) return rc;
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, N, (const unsigned *)c->proxy.as<unsigned>(), c->order.as<int>());
+    }
+    for (int k = 0; k < nt; ++k) {
+        if ((rc = launch_tier(k, two_phase ? 2 : 0, false))) return rc;
+        if (overlap && k == 0) {
+            // tier 1 alongside tier 0: queued on the side stream behind the predictor only; its workgroups start when
+            // tier 0's persistent workgroups begin to leave CUs.  The main stream then waits for it, and the ordinary
+            // launch of tier 1 that follows picks up whatever it left (normally nothing).
+            HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            if ((rc = launch_tier(1, 0, true))) return rc;
+            HIPCHK(hipEventRecord(c->ev_join, c->aux_stream));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0));
+        }
         if ((need_hbm_tier && k == nt - 2) || (!need_hbm_tier && k == nt - 1) || nt == 1) HIPCHK(hipEventRecord(e2, st));   // after the last LDS tier
     }
     HIPCHK(hipEventRecord(e3, st));
@@ -620,9 +660,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());

@@ -198,11 +198,13 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 const int *__restrict__ k_count,
                                                 const double *__restrict__ other_x,
                                                 const double *__restrict__ other_v, CarTab tab,
-                                                unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */) {
+                                                unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */,
+                                                int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 64) counters[e] = 0u;
     if (e >= N) return;
     if (ubound) ubound[e] = 0ull;
+    if (queue1) queue1[e] = -1;
     DState<KMAX> s;
     s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
     double start_s = ego[e * 5 + 4];
@@ -312,6 +314,9 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
 }
 
 #define STMPC_MAX_TIERS 6
+#define STMPC_CNT_CONSUMED 32   // + 2*tier + {0 unbounded, 1 bounded}: entries of the tier's queue handed out
+#define STMPC_CNT_RESIDENT 48   // workgroups of the first launch that have started
+#define STMPC_CNT_FINISHED 49   // ... and that have exited
 #define STMPC_CNT_ERR 63
 #define STMPC_CNT_RETRY 62
 #define STMPC_CNT_NODES_EXACT 61
@@ -346,6 +351,10 @@ struct SolveArgs {
     int force_general;     // test hook: route every episode to the last tier as if its lattice were not affine
     int phase;             // 0: bound + exact in one go; 1: bounding pre-passes only (writes ubound, proxy); 2: exact, bound from ubound
     const int *order;      // tier-0 episode order for phase 2 (heaviest first) or null
+    int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
+    int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
+    int prev_grid;         // workgroups of the producing launch (concurrent consumer: all must be resident, all must finish)
+    unsigned long long wait_ticks;   // concurrent consumer: give up waiting after this many 100 MHz ticks
     unsigned *proxy;       // [N] work estimate written by phase 1 (nodes the pre-passes expanded)
     // outputs
     int *path_idx;         // [N][H]
@@ -1081,6 +1090,33 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
         if (rc != 0 && tid == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
+        // Queue of an overflow tier: episodes without a cost bound (the expensive ones) grow from the front of the
+        // tier's list, the others from the back; unbounded ones are handed out first to keep the launch's tail short.
+        // A concurrent launch (a.concurrent) starts on CUs the previous tier's persistent workgroups have already
+        // left and consumes the queue while it is still being filled: entries are published with release stores
+        // into slots preset to -1, tickets are taken by compare-and-swap only when an entry exists, and the launch
+        // ends when the producers have all exited and the queue is drained.  It never waits unless every producer
+        // workgroup is resident (so the producers cannot be waiting for this launch's CUs), and not longer than
+        // a.wait_ticks; whatever it leaves is picked up by the ordinary launch of the tier that follows.
+        auto claim = [&](int which) -> int {
+            unsigned *consumed = &a.counters[STMPC_CNT_CONSUMED + 2 * a.tier + which];
+            unsigned *total = &a.counters[4 * a.tier + 2 + which];
+            for (;;) {
+                const unsigned c = __hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned t = __hip_atomic_load(total, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (c >= t) return -1;
+                if (atomicCAS(consumed, c, c + 1u) != c) continue;
+                int *slot = &a.lists[(size_t)a.tier * a.N + (which == 0 ? c : (unsigned)a.N - 1u - c)];
+                int e_;
+                do { e_ = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (e_ < 0 && a.concurrent);
+                return e_;
+            }
+        };
+        const unsigned long long t_begin = a.concurrent ? wall_clock64() : 0ull;
+        if (a.tier == 0 && a.feeds_concurrent && tid == 0) atomicAdd(&a.counters[STMPC_CNT_RESIDENT], 1u);
+        bool may_wait = false;
+        if (a.concurrent && tid == 0)
+            may_wait = __hip_atomic_load(&a.counters[STMPC_CNT_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.prev_grid;
         for (;;) {
             __syncthreads();
             if (tid == 0) {
@@ -1089,13 +1125,18 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
                     unsigned w = atomicAdd(&a.counters[a.phase == 1 ? 2 : 0], 1u);
                     if (w < (unsigned)a.N) e = a.order ? a.order[w] : (int)w;
                 } else {
-                    // the tier's queue: episodes without a cost bound (the expensive ones) from the front, the others
-                    // from the back of the same array; heaviest first keeps the tail of this launch short
-                    unsigned w = atomicAdd(&a.counters[4 * a.tier + 1], 1u);
-                    unsigned cnt = __hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned heavy = __hip_atomic_load(&a.counters[4 * a.tier + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w < heavy) e = a.lists[(size_t)a.tier * a.N + w];
-                    else if (w < cnt) e = a.lists[(size_t)a.tier * a.N + (a.N - 1 - (w - heavy))];
+                    for (;;) {
+                        e = claim(0);
+                        if (e < 0) e = claim(1);
+                        if (e >= 0 || !a.concurrent || !may_wait) break;
+                        if (__hip_atomic_load(&a.counters[STMPC_CNT_FINISHED], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.prev_grid) {
+                            e = claim(0);                          // producers are gone: whatever is queued now is final
+                            if (e < 0) e = claim(1);
+                            break;
+                        }
+                        if (wall_clock64() - t_begin > a.wait_ticks) break;
+                        __builtin_amdgcn_s_sleep(64);
+                    }
                 }
                 sh.work = e;
             }
@@ -1109,12 +1150,15 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
                     const u64 ub = a.ubound ? a.ubound[e] : 0ull;          // written by this thread in solve_episode
                     const bool heavy = (ub == 0ull || ub == INF_BITS);
                     const unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1) + (heavy ? 2 : 3)], 1u);
-                    a.lists[(size_t)(a.tier + 1) * a.N + (heavy ? pos : (unsigned)a.N - 1u - pos)] = e;
+                    int *slot = &a.lists[(size_t)(a.tier + 1) * a.N + (heavy ? pos : (unsigned)a.N - 1u - pos)];
+                    __hip_atomic_store(slot, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // after ubound[e]
                 } else {
                     atomicExch(&a.counters[STMPC_CNT_ERR], 1u);   // the last tier's window covers all S cells
                 }
             }
         }
+        if (a.tier == 0 && a.feeds_concurrent && tid == 0)
+            __hip_atomic_fetch_add(&a.counters[STMPC_CNT_FINISHED], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -325,3 +325,27 @@ def test_random_parameter_sets_match_oracle(seed, gpu_ctx, restore_settings):
     res = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
     ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=8)
     _check(res, ref, H)
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_concurrent_overflow_launch_is_exact(overlap, restore_settings, monkeypatch):
+    """More episodes than persistent workgroups on the wide lattice: with STMPC_OVERLAP=1 the second LDS window's launch
+    runs on a side stream and consumes the overflow queue while the first launch is still filling it; results must
+    not depend on it."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    monkeypatch.setenv("STMPC_OVERLAP", overlap)
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    ego, kc, ox, ov = synth.generate_states(1400, k=6, kmax=8, seed=4321)
+    ctx = _capi.Context(0)
+    for rep in range(2):                       # second call: queues and counters are re-initialised per launch
+        res = st.solve_arrays(ego, kc, ox, ov, p, ctx)
+    s = ctx.stats()
+    assert s["fallback"] > 20 and s["hbm_tier"] == 0
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=16)
+    _check(res, ref, 40)
+    ctx.close()
