@@ -28,7 +28,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--episodes", type=int, default=4096, help="episodes per GPU")
-    ap.add_argument("--workload", choices=["h40a21", "default"], default="h40a21")
+    ap.add_argument("--workload", choices=["h40a21", "default", "control"], default="h40a21",
+                    help="h40a21: BASELINE workload; default: the reference's own lattice; control: st.do_st_control on the "
+                         "reference's lattice (lattice search + QP re-sampling + commanded speed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
     args = ap.parse_args()
@@ -76,12 +78,21 @@ def main():
     d_pd = torch.empty((n, H), dtype=torch.float64, device=dev)
     d_crash = torch.empty(n, dtype=torch.int32, device=dev)
     gathered = torch.empty((n * world, 2), dtype=torch.float64, device=dev) if use_dist else None
+    control = args.workload == "control"
+    d_speed = torch.empty(n, dtype=torch.float64, device=dev) if control else None
+    d_fine = torch.zeros((n, _capi.QP_NMAX), dtype=torch.float64, device=dev) if control else None
+    d_fine_len = torch.zeros(n, dtype=torch.int32, device=dev) if control else None
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
-        ctx.solve_batch_device(params, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
-                               d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_pd.data_ptr(),
-                               d_crash.data_ptr(), stream)
+        if control:
+            ctx.st_control_batch_device(params, pkg.Settings.TICK_LENGTH, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(),
+                                        d_ox.data_ptr(), d_ov.data_ptr(), d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(),
+                                        d_speed.data_ptr(), d_fine.data_ptr(), d_fine_len.data_ptr(), stream)
+        else:
+            ctx.solve_batch_device(params, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
+                                   d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_pd.data_ptr(),
+                                   d_crash.data_ptr(), stream)
         if use_dist:
             sharding.gather_actions(sharding.pack_actions(d_path, d_cost), world, gathered, force=True)
 
@@ -126,7 +137,9 @@ def main():
                 "note": "algorithmic HBM bytes are %d B/solve (SURVEY 8d): the path is fp64-VALU/LDS bound, not HBM bound; "
                         "see fp64_valu for the bound that applies" % bytes_per_solve}
 
-    out = {"metric": "MPC solves/sec (H=40,A=21,K=6)" if args.workload == "h40a21" else "MPC solves/sec (reference default H=18,S=3001,K=6)",
+    metric = {"h40a21": "MPC solves/sec (H=40,A=21,K=6)", "default": "MPC solves/sec (reference default H=18,S=3001,K=6)",
+              "control": "st.do_st_control commanded speeds/sec (reference default H=18,S=3001,K=6, QP re-sampling to the 0.2 s tick)"}[args.workload]
+    out = {"metric": metric,
            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
@@ -140,6 +153,10 @@ def main():
                      "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]),
                      "nodes_expanded_per_solve": (tier_stats["nodes_exact"] + tier_stats["nodes_bound"]) / n}}
 
+    if control:
+        out["stages"] = {"lattice_search_ms": prof["solve_ms"] / max(prof["launches"], 1),
+                         "qp_resampling_ms": ms_per_step - prof["solve_ms"] / max(prof["launches"], 1),
+                         "note": "lattice search from HIP events inside the library; QP = step time minus that"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import st_oracle as orc
         op = orc.OrcParams.from_dict(params.as_dict())
@@ -158,10 +175,30 @@ def main():
         flops = 27 * ref["edges"] + 26 * ref["nodes"] + 6 * K * ref["cells"] + 40 * K * H * m
         got = {"path_idx": d_path[:m].cpu().numpy(), "best_t": d_bt[:m].cpu().numpy(), "cost": d_cost[:m].cpu().numpy(),
                "crash": d_crash[:m].cpu().numpy()}
+        if control:
+            got.pop("crash")                                   # the controller entry does not compute the crash probe
         parity = {k: bool(np.array_equal(got[k], ref[k])) for k in got}
+        if control:
+            # the QP stage on the host: the oracle's restatement, one episode at a time (single thread)
+            from oracle import ff_oracle as ff
+            from rl_mpc_lanemerging_amd import st as st_mod
+            S_ = pkg.Settings
+            fs = ff.settings(S_.MAX_SPEED, S_.MAX_POSITIVE_ACCELERATION, S_.MAX_NEGATIVE_ACCELERATION, S_.MAXIMUM_POSITIVE_JERK,
+                             S_.MINIMUM_NEGATIVE_JERK, S_.CAR_LENGTH)
+            mq = min(m, 2048)
+            want = np.zeros(mq)
+            c0 = time.perf_counter()
+            for i in range(mq):
+                bt_i = int(ref["best_t"][i])
+                s_seq = st_mod.s_values_for(ego[i, 4], params)[ref["path_idx"][i, :bt_i + 1]]
+                x = ff.finer_fit(s_seq, S_.TICK_LENGTH, S_.T_DISCRETIZATION, ego[i, 2], ego[i, 3], fs)[0]
+                want[i] = ego[i, 2] if len(x) <= 1 else (x[1] - x[0]) / S_.TICK_LENGTH
+            qp_s = time.perf_counter() - c0
+            parity["speed"] = bool(np.array_equal(d_speed[:mq].cpu().numpy(), want))
+            cpu_s += qp_s * (m * reps / mq)                    # as if every solved episode had also been re-sampled (1 thread)
         out["cpu_baseline"] = {"value": m * reps / cpu_s, "unit": "solves/s", "cores": cores, "kind": "port",
-                               "sample": "first %d episodes of the same batch x %d repeats, oracle layered DP (oracle/st_oracle.c), %d threads, %.1f s"
-                                         % (m, reps, cores, cpu_s)}
+                               "sample": "first %d episodes of the same batch x %d repeats, oracle layered DP (oracle/st_oracle.c), %d threads, %.1f s%s"
+                                         % (m, reps, cores, cpu_s, " incl. the QP stage (oracle/ff_oracle.c) on 1 thread, scaled from %d episodes" % min(m, 2048) if control else "")}
         out["parity_vs_oracle"] = {"episodes": m, **parity}
         flops_per_solve = flops / m
         out["fp64_valu"] = {"algorithmic_flops_per_solve": flops_per_solve,
