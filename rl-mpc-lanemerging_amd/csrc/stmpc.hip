@@ -96,6 +96,7 @@ struct stmpc_ctx {
     int last_nt = 0;
     bool last_has_hbm = true;
     // STMPC_OVERLAP=0/1: start the second LDS tier on its own stream while the first is still running (see k_solve)
+    bool split = true;             // STMPC_SPLIT=0/1: bounding and exact pass of an episode are separate tasks of the first launch (-4 % at N=4096)
     int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -186,6 +187,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
+    if (const char *w = getenv("STMPC_SPLIT")) c->split = atoi(w) != 0;
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
     int prio_least = 0, prio_greatest = 0;
@@ -294,9 +296,9 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, hipStream_t st) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0);
 }
 
 }  // namespace
@@ -399,10 +401,12 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const bool overlap = nt >= 2 && tierLds[1] && !(prune_on && c->two_phase) && N > tierGrid[0] &&
                          (c->overlap < 0 ? prune_on != 0 : c->overlap != 0);
     int *queue1 = overlap ? c->lists.as<int>() + (size_t)N : nullptr;
+    const bool split = prune_on && !c->two_phase && c->split && N >= 2 * tierGrid[0];
+    unsigned *proxy0 = split ? c->proxy.as<unsigned>() : nullptr;
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -428,6 +432,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     auto launch_tier = [&](int k, int phase, bool side) -> int {
         hipStream_t lst = side ? c->aux_stream : st;
         a.concurrent = side ? 1 : 0;
+        a.split = (split && k == 0) ? 1 : 0;
         a.feeds_concurrent = (overlap && k == 0) ? 1 : 0;
         a.prev_grid = side ? tierGrid[0] : 0;
         a.wait_ticks = side ? 20000000ull : 0ull;             // 0.2 s of the 100 MHz clock
@@ -664,9 +669,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());

@@ -199,12 +199,14 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 const double *__restrict__ other_x,
                                                 const double *__restrict__ other_v, CarTab tab,
                                                 unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */,
-                                                int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */) {
+                                                int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */,
+                                                unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 64) counters[e] = 0u;
     if (e >= N) return;
     if (ubound) ubound[e] = 0ull;
     if (queue1) queue1[e] = -1;
+    if (proxy0) proxy0[e] = 0u;
     DState<KMAX> s;
     s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
     double start_s = ego[e * 5 + 4];
@@ -314,6 +316,7 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
 }
 
 #define STMPC_MAX_TIERS 6
+#define STMPC_PROXY_MOVED 0xffffffffu   // split tasks: the bounding task sent the episode to the next tier
 #define STMPC_CNT_CONSUMED 32   // + 2*tier + {0 unbounded, 1 bounded}: entries of the tier's queue handed out
 #define STMPC_CNT_RESIDENT 48   // workgroups of the first launch that have started
 #define STMPC_CNT_FINISHED 49   // ... and that have exited
@@ -351,6 +354,7 @@ struct SolveArgs {
     int force_general;     // test hook: route every episode to the last tier as if its lattice were not affine
     int phase;             // 0: bound + exact in one go; 1: bounding pre-passes only (writes ubound, proxy); 2: exact, bound from ubound
     const int *order;      // tier-0 episode order for phase 2 (heaviest first) or null
+    int split;             // tier 0 hands out 2N tasks: the bounding pre-passes of all episodes, then their exact passes
     int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
     int prev_grid;         // workgroups of the producing launch (concurrent consumer: all must be resident, all must finish)
@@ -891,7 +895,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
-                             double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n) {
+                             double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n, const int phase) {
     const DevP &p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -915,7 +919,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     if constexpr (!S1GEN) {
         // this variant evaluates s_values[n] as start + n*delta for every n; the (very rare) episode whose second
         // lattice point start+step differs from that goes to the last tier, which is compiled with the general form
-        if ((!ep.s1_plain || a.force_general) && a.phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
+        if ((!ep.s1_plain || a.force_general) && phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
     }
     ep.bp = a.bp + (size_t)slot * H * W;
     const double start_s = ep.start_s, delta = ep.delta;
@@ -947,7 +951,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     u64 ubits = INF_BITS;
     bool have_bound = false;
     if constexpr (!GRID) {
-        if (a.prune && (a.tier > 0 || a.phase == 2)) {   // bounded earlier (bound-only phase, or the tier it overflowed)
+        if (a.prune && (a.tier > 0 || phase == 2)) {   // bounded earlier (bound-only phase, or the tier it overflowed)
             const u64 ub = a.ubound[e];
             if (ub != 0ull) { ubits = ub; have_bound = true; }
         }
@@ -962,11 +966,15 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
-            if (rc != 0 && !a.last_tier) return rc;
-            if (a.phase == 1) {                               // bound-only phase: publish the bound and a work estimate
+            if (rc != 0 && !a.last_tier) {
+                if (phase == 1 && a.split && tid == 0)        // tell this episode's exact task that the episode has moved on
+                    __hip_atomic_store(&a.proxy[e], STMPC_PROXY_MOVED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return rc;
+            }
+            if (phase == 1) {                                 // bound-only task: publish the bound and a work estimate
                 if (tid == 0) {
-                    a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;
                     a.proxy[e] = (ubits == INF_BITS) ? 0x3fffffffu : (unsigned)bn;     // unbounded episodes are the heaviest
+                    __hip_atomic_store(&a.ubound[e], (ubits == 0ull) ? 1ull : ubits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return 0;
             }
@@ -1086,7 +1094,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
     u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
-        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX, true>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
+        int rc = solve_episode<USE_LDS, true, FASTDIV, 0, FANMAX, true>(a, 0, 0, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, 0);
         if (rc != 0 && tid == 0) atomicExch(&a.counters[STMPC_CNT_ERR], 1u);
         return;
     } else {
@@ -1121,9 +1129,28 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
             __syncthreads();
             if (tid == 0) {
                 int e = -1;
-                if (a.tier == 0) {
+                int task_phase = a.phase;
+                if (a.tier == 0 && a.split) {
+                    // 2N tasks: bounding pre-passes of all episodes first, then the exact passes in the same order --
+                    // finer-grained tasks pack the persistent workgroups better.  An exact task is handed out at
+                    // least N tasks after its bounding task, which is therefore long finished; the wait below only
+                    // covers the pathological case.
+                    unsigned w = atomicAdd(&a.counters[0], 1u);
+                    if (w < (unsigned)a.N) { e = (int)w; task_phase = 1; }
+                    else if (w < 2u * (unsigned)a.N) {
+                        e = (int)(w - (unsigned)a.N); task_phase = 2;
+                        for (;;) {
+                            const unsigned px = __hip_atomic_load(&a.proxy[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            if (px == STMPC_PROXY_MOVED) { task_phase = 3; break; }      // nothing left to do here
+                            if (__hip_atomic_load(&a.ubound[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+                            __builtin_amdgcn_s_sleep(32);
+                        }
+                    }
+                    sh.rc = task_phase;
+                } else if (a.tier == 0) {
                     unsigned w = atomicAdd(&a.counters[a.phase == 1 ? 2 : 0], 1u);
                     if (w < (unsigned)a.N) e = a.order ? a.order[w] : (int)w;
+                    sh.rc = a.phase;
                 } else {
                     for (;;) {
                         e = claim(0);
@@ -1143,7 +1170,9 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
             __syncthreads();
             const int e = sh.work;
             if (e < 0) break;
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n);
+            const int task_phase = (a.tier == 0) ? sh.rc : a.phase;
+            if (task_phase == 3) continue;
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
