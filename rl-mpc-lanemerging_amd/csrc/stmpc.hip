@@ -69,6 +69,7 @@ struct stmpc_ctx {
     DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, proxy, order, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
+    DevBuf ckpt, resume_t;
     DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
@@ -96,6 +97,7 @@ struct stmpc_ctx {
     int last_nt = 0;
     bool last_has_hbm = true;
     // STMPC_OVERLAP=0/1: start the second LDS tier on its own stream while the first is still running (see k_solve)
+    bool resume = true;            // STMPC_RESUME=0/1: the wider window continues a checkpointed exact pass instead of starting over
     bool split = true;             // STMPC_SPLIT=0/1: bounding and exact pass of an episode are separate tasks of the first launch (-4 % at N=4096)
     int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
     hipStream_t aux_stream = nullptr;
@@ -188,6 +190,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_SPLIT")) c->split = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
     int prio_least = 0, prio_greatest = 0;
@@ -208,7 +211,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
-                     &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
+                     &c->ckpt, &c->resume_t, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -296,9 +299,9 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, hipStream_t st) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t);
 }
 
 }  // namespace
@@ -378,10 +381,23 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
         tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     }
+    const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
+    // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
+    // episode (N x H x W0 x 2 B) instead of per resident workgroup
+    const size_t bp0_per_episode = (size_t)N * H * tierW[0] * sizeof(u16);
+    const bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
+                        bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
     for (int k = 0; k < nt; ++k) {
         if (tierGrid[k] > N) tierGrid[k] = N;
-        if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * sizeof(u16)))) return rc;
+        const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * sizeof(u16);
+        if ((rc = c->bp_tier[k].ensure(need))) return rc;
     }
+    const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
+    if (resume) {
+        if ((rc = c->ckpt.ensure((size_t)N * ckpt_stride))) return rc;
+        if ((rc = c->resume_t.ensure((size_t)N * sizeof(int)))) return rc;
+    }
+    int *resume_t = resume ? c->resume_t.as<int>() : nullptr;
     if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8)))) return rc;
 
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
@@ -395,7 +411,6 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         e0 = c->pool[c->pool_used]; e1 = c->pool[c->pool_used + 1]; e2 = c->pool[c->pool_used + 2]; e3 = c->pool[c->pool_used + 3];
         c->pool_used += 4;
     }
-    const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // second LDS tier started alongside the first (see k_solve): only where overflow is common enough to pay for the
     // extra launch, and not with the two-phase schedule (its first launch of tier 0 only bounds)
     const bool overlap = nt >= 2 && tierLds[1] && !(prune_on && c->two_phase) && N > tierGrid[0] &&
@@ -404,9 +419,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const bool split = prune_on && !c->two_phase && c->split && N >= 2 * tierGrid[0];
     unsigned *proxy0 = split ? c->proxy.as<unsigned>() : nullptr;
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -420,6 +435,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.band = c->band_override > 0 ? c->band_override : fmax(1.0, 0.5 * dp.v_w * dp.v_des * dp.v_des);
     a.band2_mult = c->band2_mult;
     a.force_general = c->force_general ? 1 : 0;
+    a.ckpt = resume ? c->ckpt.as<unsigned char>() : nullptr; a.ckpt_stride = ckpt_stride; a.resume_t = resume_t;
+    a.W0 = tierW[0];
+    a.maxshift = (int)ceil(dp.v_max * dp.dt / dp.ds) + 2 + 66;     // st_cy.pyx:65-93: v <= v_max; + interval rounding to 64-cell blocks
     a.proxy = c->proxy.as<unsigned>();
     const bool two_phase = a.prune && c->two_phase;      // bound all episodes first, then solve them heaviest-first
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
@@ -440,15 +458,25 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.order = (phase == 2 && k == 0) ? c->order.as<int>() : nullptr;
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
+        a.bp0 = (resume && k >= 1) ? c->bp_tier[0].as<u16>() : nullptr;
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
         const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
-#define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
+#define STMPC_LAUNCH_R(L, FD, KT_, FM, SG, RS)                                                                \
         do {                                                                                                  \
             if (lds > 48 * 1024)                                                                              \
-                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG>,                  \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG, RS>,              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG>), grid, block, lds, lst, a);               \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS>), grid, block, lds, lst, a);           \
+        } while (0)
+        // checkpointing variants only where they are used: the first window saves, the second continues
+#define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
+        do {                                                                                                  \
+            if constexpr (L && FM == 12 && KT_ == 0) {                                                        \
+                if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                                  \
+                else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
+                else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                   \
+            } else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                     \
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
@@ -462,6 +490,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 #undef STMPC_LAUNCH_FM
 #undef STMPC_LAUNCH
 #undef STMPC_LAUNCH_S
+#undef STMPC_LAUNCH_R
         return STMPC_OK;
     };
 
@@ -669,9 +698,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());

@@ -200,13 +200,15 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 const double *__restrict__ other_v, CarTab tab,
                                                 unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */,
                                                 int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */,
-                                                unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */) {
+                                                unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */,
+                                                int *resume_t /* [N] or null: zeroed here */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 64) counters[e] = 0u;
     if (e >= N) return;
     if (ubound) ubound[e] = 0ull;
     if (queue1) queue1[e] = -1;
     if (proxy0) proxy0[e] = 0u;
+    if (resume_t) resume_t[e] = 0;
     DState<KMAX> s;
     s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
     double start_s = ego[e * 5 + 4];
@@ -354,6 +356,16 @@ struct SolveArgs {
     int force_general;     // test hook: route every episode to the last tier as if its lattice were not affine
     int phase;             // 0: bound + exact in one go; 1: bounding pre-passes only (writes ubound, proxy); 2: exact, bound from ubound
     const int *order;      // tier-0 episode order for phase 2 (heaviest first) or null
+    // Checkpoint / resume of the exact pass across window tiers: when the layer about to be built cannot fit the
+    // first window, the pass saves the finished layer (costs + histories of its live cells) and the episode moves
+    // on; the wider window loads it and continues from that layer instead of starting over.  Back-pointers of the
+    // finished layers stay where tier 0 wrote them (one region per episode).
+    unsigned char *ckpt;   // [N][ckpt_stride] or null: header {layer, wlo, whi, flags} + cost[W0] + hist[W0]
+    size_t ckpt_stride;
+    int *resume_t;         // [N] layer to resume at (0 = start over); written before the episode is queued
+    const u16 *bp0;        // tier >= 1: tier 0's per-episode back-pointers (row stride W0) or null
+    int W0;                // first window (cells)
+    int maxshift;          // upper bound of (target cell - source cell) + rounding slack of the interval bookkeeping
     int split;             // tier 0 hands out 2N tasks: the bounding pre-passes of all episodes, then their exact passes
     int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
@@ -457,10 +469,40 @@ enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 //   -- barrier --
 //   C  candidates that met an equal value and still match the final cost: atomic_min(hist[cell], key);
 //      key has the predecessor index in the high half, so the smaller predecessor wins (st_cy.pyx:388 order)
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN>
+// Checkpoint of a finished layer (see SolveArgs::ckpt).  Kept out of line: these run once per overflowing episode and
+// must not cost the lattice loop any registers.
+template <bool USE_LDS>
+__device__ __attribute__((noinline)) void ckpt_save(unsigned char *ck, int W0, const u64 *cost, const unsigned *hist, int WM,
+                                                    int t, int wlo, int whi, int flags) {
+    typedef Mem<USE_LDS> M;
+    u64 *ck_cost = (u64 *)(ck + 16);
+    unsigned *ck_hist = (unsigned *)(ck + 16 + (size_t)W0 * 8);
+    for (int n = wlo + (int)threadIdx.x; n < whi; n += (int)blockDim.x) {
+        ck_cost[n - wlo] = M::ld64(&cost[n & WM]);
+        ck_hist[n - wlo] = M::ld32(&hist[n & WM]);
+    }
+    if (threadIdx.x == 0) { int *hd = (int *)ck; hd[0] = t; hd[1] = wlo; hd[2] = whi; hd[3] = flags; }
+}
+template <bool USE_LDS>
+__device__ __attribute__((noinline)) void ckpt_load(const unsigned char *ck, int W0, u64 *cost, unsigned *hist, int WM,
+                                                    int *wlo_out, int *whi_out, int *flags_out) {
+    typedef Mem<USE_LDS> M;
+    const int *hd = (const int *)ck;
+    const int wlo = hd[1], whi = hd[2];
+    const u64 *ck_cost = (const u64 *)(ck + 16);
+    const unsigned *ck_hist = (const unsigned *)(ck + 16 + (size_t)W0 * 8);
+    for (int n = wlo + (int)threadIdx.x; n < whi; n += (int)blockDim.x) {
+        M::st64(&cost[n & WM], ck_cost[n - wlo]);
+        M::st32(&hist[n & WM], ck_hist[n - wlo]);
+    }
+    *wlo_out = wlo; *whi_out = whi; *flags_out = hd[3];
+}
+
+// RES: 0 no checkpointing, 1 this tier saves a layer it cannot build (first window), 2 this tier may continue from one
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN, int RES = 0>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
                        u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
-                       u64 ubits, double band, bool hardsoft, PassOut &out) {
+                       u64 ubits, double band, bool hardsoft, PassOut &out, const int t_start = 0) {
     typedef Mem<USE_LDS> M;
     const DevP &p = a.p;
     const int tid = threadIdx.x;
@@ -490,16 +532,20 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
 
     M::barrier();                       // previous users of the arrays are done
-    if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
-    M::barrier();
     int wlo = 0, whi = 1;
+    if (RES == 2 && t_start > 0) {      // continue a pass checkpointed by the first window (see SolveArgs::ckpt)
+        int fl = 0;
+        ckpt_load<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
+        if (tid == 0) sh.flags = fl;
+    } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
+    M::barrier();
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
     int total_nodes = 0;
     int maxspan = 0;
 
     const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
-    for (int t = 0; t <= last_src_layer; ++t) {
+    for (int t = t_start; t <= last_src_layer; ++t) {
         const bool relax = t < H - 1;
         int ilo = 0, ihi = 0;
         bool first = true;
@@ -658,6 +704,15 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
             }
             out.best_t = t; out.best_n = bn; out.best_bits = bb;
+            if (RES == 1 && relax && t > 0) {
+                // will layer t+1 fit?  Every target lies within maxshift cells above its source, so the live span of
+                // the layer about to be built is at most (highest source + maxshift) - lowest source.
+                const int top_src = list_at(0), low_src = list_at(nlist - 1);
+                if (top_src + a.maxshift - low_src > W) {
+                    ckpt_save<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
+                    return 2;
+                }
+            }
         }
 
         // ---- expand: rounds of 64*NW listed sources, highest cells first
@@ -893,7 +948,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 }
 
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
                              double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n, const int phase) {
     const DevP &p = a.p;
@@ -921,7 +976,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         // lattice point start+step differs from that goes to the last tier, which is compiled with the general form
         if ((!ep.s1_plain || a.force_general) && phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
     }
-    ep.bp = a.bp + (size_t)slot * H * W;
+    ep.bp = a.bp + (size_t)(RES == 1 ? e : slot) * H * W;      // RES 1: per episode, the next tier reads them
     const double start_s = ep.start_s, delta = ep.delta;
     const int S = ep.S;
     auto sval = [&](int n) -> double {
@@ -980,10 +1035,18 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             }
         }
     }
+    int t_res = 0;                      // layer the successful pass started from (checkpoint of the first window) or 0
+    if constexpr (RES == 2) { if (have_bound) t_res = a.resume_t[e]; }
     for (int attempt = 0;; ++attempt) {
-        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out);
+        if (attempt > 0) t_res = 0;     // a relaxed bound invalidates the checkpoint: start over
+        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN, RES>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out, t_res);
         if (rc != 0) {
-            if constexpr (!GRID) { if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits; }   // 0 is reserved for "unknown"
+            if constexpr (!GRID) {
+                if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;    // 0 is reserved for "unknown"
+                if constexpr (RES == 1) { if (tid == 0) a.resume_t[e] = (rc == 2) ? out.best_t : 0; }   // rc 2: layer out.best_t is saved
+                __threadfence();        // checkpoint, back-pointers, bound: visible before the episode is queued
+                __syncthreads();
+            }
             return rc;
         }
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
@@ -1005,7 +1068,8 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         int n = best_n;
         for (int t = best_t; t > 0; --t) {
             sh.path[t] = n;
-            n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (RES != 2 || t >= t_res) n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else n = __hip_atomic_load(&a.bp0[((size_t)e * H + t) * a.W0 + (n & (a.W0 - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         sh.path[0] = n;
     }
@@ -1070,7 +1134,7 @@ __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 
 __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_t)H * KT * 24 + (((size_t)H * 4 + 7) & ~(size_t)7); }
 
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0>
 __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
@@ -1172,7 +1236,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs
             if (e < 0) break;
             const int task_phase = (a.tier == 0) ? sh.rc : a.phase;
             if (task_phase == 3) continue;
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN, RES>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);

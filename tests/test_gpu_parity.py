@@ -327,15 +327,17 @@ def test_random_parameter_sets_match_oracle(seed, gpu_ctx, restore_settings):
     _check(res, ref, H)
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_concurrent_overflow_launch_is_exact(overlap, restore_settings, monkeypatch):
+@pytest.mark.parametrize("overlap,resume", [("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")])
+def test_concurrent_overflow_launch_is_exact(overlap, resume, restore_settings, monkeypatch):
     """More episodes than persistent workgroups on the wide lattice: with STMPC_OVERLAP=1 the second LDS window's launch
-    runs on a side stream and consumes the overflow queue while the first launch is still filling it; results must
-    not depend on it."""
+    runs on a side stream and consumes the overflow queue while the first launch is still filling it; with
+    STMPC_RESUME=1 it continues exact passes from the layer the first window checkpointed instead of starting over.
+    Results must not depend on either."""
     import rl_mpc_lanemerging_amd as pkg
     from rl_mpc_lanemerging_amd import _capi, st, synth
     from oracle import st_oracle as orc
     monkeypatch.setenv("STMPC_OVERLAP", overlap)
+    monkeypatch.setenv("STMPC_RESUME", resume)
     pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
     pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
     p = _capi.Params.from_settings(pkg.Settings)
