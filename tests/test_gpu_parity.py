@@ -378,3 +378,22 @@ def test_limits_of_the_interface(name, over, n, k, kmax, restore_settings):
     if name == "S=30001,H=40":
         assert ctx.stats()["hbm_tier"] > 0
     ctx.close()
+
+
+def test_batch_sizes_around_the_scheduling_thresholds(restore_settings):
+    """One context, batch sizes on both sides of the thresholds that switch on task splitting, the side launch and the
+    checkpointing (multiples of the persistent grid), in mixed order: buffers are re-sized, queues and counters re-set."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    ego, kc, ox, ov = synth.generate_states(2600, k=6, kmax=8, seed=99)
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=16)
+    ctx = _capi.Context(0)
+    for n in (2600, 1, 1025, 2047, 2049, 300, 2600, 1024):
+        res = st.solve_arrays(ego[:n], kc[:n], ox[:n], ov[:n], p, ctx)
+        _check(res, {q: ref[q][:n] for q in ("path_idx", "best_t", "cost", "crash", "path_dist")}, 40)
+    ctx.close()
