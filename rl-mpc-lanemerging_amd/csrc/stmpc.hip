@@ -195,8 +195,13 @@ int stmpc_create(stmpc_ctx **out, int device) {
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        c->aux_stream = nullptr;
+        if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
+    }
+    if (!c->aux_stream) c->overlap = 0;          // no side stream: the tiers simply run one after the other
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         stmpc_destroy(c);
         return fail(STMPC_EHIP, "stream/event creation failed");
