@@ -842,7 +842,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (first) { ilo = ihi = clo; first = false; }
             const int nlo2 = clo < ilo ? clo : ilo, nhi2 = chi > ihi ? chi : ihi;
             if (nhi2 - smin > maxspan) maxspan = nhi2 - smin;
-            if (nhi2 - smin > W) return 1;                                   // live cells exceed the circular window
+            bool last_round = false;
+            if (nhi2 - smin > W) {                                           // live cells exceed the circular window
+                // the bounding pre-pass may drop anything: it gives up the layer's remaining (lowest, slowest) sources
+                // instead of the window, as long as the layer being built fits on its own
+                if (MODE == PASS_BOUND && nhi2 - a_k <= W) last_round = true;
+                else return 1;
+            }
             if (chi - clo > PW) return 1;                                    // 64 sources' targets exceed the penalty buffer
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
@@ -923,6 +929,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     }
                 }
             }
+            if (last_round) break;
         }
 
         // ---- end of layer.  PASS_EXACT needs no barrier here: the next scan only reads cost[] (final since the
