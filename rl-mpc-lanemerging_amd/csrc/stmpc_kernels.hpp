@@ -337,6 +337,7 @@ struct SolveArgs {
     int last_tier;         // overflow here is an internal error
     int prune;             // 1: bound the exact pass by a banded pre-pass (dp_pass PASS_BOUND)
     double band;           // cost band of the pre-pass
+    int band_cap;          // > 0: the pre-pass steers its band towards this many expanded nodes per layer
     double band2_mult;     // the second pre-pass attempt (penalty zone allowed) uses band * band2_mult
     // table mode inputs
     const double *ego;     // [N][5]
@@ -541,6 +542,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     M::barrier();
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
+    double bandt = band;           // PASS_BOUND: the band in force, steered towards a.band_cap expanded nodes per layer
     int total_nodes = 0;
     int maxspan = 0;
 
@@ -554,7 +556,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         u64 my_min_tot = ~0ull;
         u64 thr = ubits;
         if constexpr (MODE == PASS_BOUND) {
-            const double lim = __longlong_as_double((long long)lmin) + band;
+            const double lim = __longlong_as_double((long long)lmin) + bandt;
             const u64 lb = (u64)__double_as_longlong(lim);
             if (lb < thr) thr = lb;
         }
@@ -696,6 +698,15 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             return (int)M::ld16(&list[w * cpw * 64 + (g - basew)]);
         };
         total_nodes += nlist;
+        if constexpr (MODE == PASS_BOUND) {
+            // beam-like control of the band: a layer that expanded more than band_cap nodes narrows the next one in
+            // proportion, a thin one lets it recover (square root), never beyond the nominal band
+            if (a.band_cap > 0 && nlist > 0) {
+                const double f = (double)a.band_cap / (double)nlist;
+                bandt = bandt * (f < 1.0 ? f : sqrt(f));
+                bandt = bandt > band ? band : (bandt < 0.05 * band ? 0.05 * band : bandt);
+            }
+        }
         if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
         if constexpr (MODE == PASS_EXACT) {
             u64 bb = ~0ull; int bn = 0x7fffffff;
@@ -793,7 +804,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         if (nk.ok && hi > lo) {
                             const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
                             const double smin_ = (nk.kv * c_v + nk.ka * c_a + nk.kj * c_j) * nk.invK;
-                            const double rad = sqrt(1.25 * band * nk.invK);
+                            const double rad = sqrt(1.25 * bandt * nk.invK);
                             const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
                             const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
                             const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
