@@ -483,7 +483,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         // checkpointing variants only where they are used: the first window saves, the second continues
 #define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
-            if constexpr (L && FM == 12 && KT_ == 0) {                                                        \
+            if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
                 if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                                  \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
                 else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                   \
@@ -491,7 +491,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
-#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 9); else STMPC_LAUNCH(L, FD, KT_, 12); } while (0)
+#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 9); else STMPC_LAUNCH(L, FD, KT_, 8); } while (0)
         if (tierLds[k]) {
             if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
             else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }
