@@ -1030,13 +1030,14 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
         if (a.prune && !have_bound) {
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
-            int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band, true, out);
-            int bn = out.nodes;
-            if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
-            else if (rc == 0) {
-                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS, a.band * a.band2_mult, false, out);
+            // (one call site in a loop: a second inlined copy of the pass would add a third to the kernel's code size)
+            int rc = 0, bn = 0;
+            for (int att = 0; att < 2; ++att) {
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
+                                                                                   att == 0 ? a.band : a.band * a.band2_mult, att == 0, out);
                 bn += out.nodes;
-                if (rc == 0 && out.best_t == H - 1) ubits = out.best_bits;
+                if (rc != 0) break;
+                if (out.best_t == H - 1) { ubits = out.best_bits; break; }
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
             if (rc != 0 && !a.last_tier) {
