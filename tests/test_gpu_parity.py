@@ -397,3 +397,19 @@ def test_batch_sizes_around_the_scheduling_thresholds(restore_settings):
         res = st.solve_arrays(ego[:n], kc[:n], ox[:n], ov[:n], p, ctx)
         _check(res, {q: ref[q][:n] for q in ("path_idx", "best_t", "cost", "crash", "path_dist")}, 40)
     ctx.close()
+
+
+@pytest.mark.parametrize("cap", ["0", "20", "300", "100000"])
+def test_band_cap_never_changes_results(cap, restore_settings, monkeypatch):
+    """The beam-like control of the pre-pass band (STMPC_BAND_CAP) only moves work between the bounding and the exact
+    pass: off, starved, default and never-binding caps give the same bits."""
+    from rl_mpc_lanemerging_amd import _capi, st
+    monkeypatch.setenv("STMPC_PRUNE", "1")
+    monkeypatch.setenv("STMPC_BAND_CAP", cap)
+    ctx = _capi.Context(0)
+    for fname in STATE_FILES:
+        g = load_golden(fname)
+        p, op = settings_from_golden(g)
+        res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
+        _check(res, g, g["t_values"].size)
+    ctx.close()
