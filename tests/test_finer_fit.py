@@ -260,3 +260,26 @@ def test_gpu_st_control_matches_oracle_pipeline(gpu_ctx):
         sv = st.s_values_for(ego[i, 4], p)
         want = ego[i, 2] if bt == 0 else (sv[ref["path_idx"][i, 1]] - sv[ref["path_idx"][i, 0]]) / 0.3
         assert res2["speed"][i] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hs,dt,cdt", [(10, 0.2, 0.3), (18, 0.2, 0.3), (40, 0.2, 0.3), (40, 0.25, 0.3)])
+def test_gpu_finer_fit_all_packings(hs, dt, cdt, gpu_ctx):
+    """4 / 2 / 1 problems per wavefront (group widths 16 / 32 / 64), ragged lengths inside one wavefront."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    p = _capi.Params.from_settings(pkg.Settings)
+    S = _ff_settings_from(pkg.Settings)
+    rng = np.random.default_rng(hs)
+    N = 130
+    seq = np.zeros((N, hs)); lens = rng.integers(1, hs + 1, N).astype(np.int32)
+    v0 = rng.uniform(0, 28, N); a0 = rng.uniform(-5, 4, N)
+    for i in range(N):
+        v = np.clip(v0[i] + np.cumsum(rng.normal(0, 1.5, hs)), 0, 30)
+        seq[i] = rng.uniform(0, 100) + np.concatenate([[0.0], np.cumsum(v[1:] * cdt)])
+    out, out_len, iters = gpu_ctx.finer_fit_batch(p, dt, cdt, seq, lens, v0, a0)
+    for i in range(N):
+        x, it, st = ff.finer_fit(seq[i, :lens[i]], dt, cdt, v0[i], a0[i], S)
+        assert out_len[i] == len(x) and np.array_equal(out[i, :len(x)], x), (i, lens[i])
+        assert iters[i] == (it if st == 0 else -it)
