@@ -243,10 +243,17 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     FFLane<NF, GW> L;
     L.lane = lane; L.n = n; L.gbase = gbase;
     {
-        int nm = n;
+        // largest n among the groups of this wavefront that are still here (a group whose path had a single point has
+        // returned: its lanes are inactive and neither hold nor forward anything, so no butterfly -- read each active
+        // group's n directly; v_readlane ignores EXEC, the ballot says which groups count)
+        const unsigned long long alive = __ballot(true);
+        int nm = 0;
 #pragma unroll
-        for (int off = 32; off >= GW; off >>= 1) { const int o = __shfl_xor(nm, off, 64); nm = (o > nm && o <= GW) ? o : nm; }
-        L.nmax = __builtin_amdgcn_readfirstlane(nm);
+        for (int g = 0; g < 64 / GW; ++g) {
+            const int ng = __builtin_amdgcn_readlane(n, g * GW);
+            if ((alive >> (g * GW)) & 1ull) nm = ng > nm ? ng : nm;
+        }
+        L.nmax = nm;
     }
     const int r = lane;
     const bool row = r < n - 1;

@@ -281,5 +281,7 @@ def test_gpu_finer_fit_all_packings(hs, dt, cdt, gpu_ctx):
     out, out_len, iters = gpu_ctx.finer_fit_batch(p, dt, cdt, seq, lens, v0, a0)
     for i in range(N):
         x, it, st = ff.finer_fit(seq[i, :lens[i]], dt, cdt, v0[i], a0[i], S)
-        assert out_len[i] == len(x) and np.array_equal(out[i, :len(x)], x), (i, lens[i])
+        # (an infeasible little QP -- contradictory acceleration and jerk rows for a 2-sample path -- diverges to NaN in
+        # the oracle and in the kernel alike)
+        assert out_len[i] == len(x) and np.array_equal(out[i, :len(x)], x, equal_nan=True), (i, lens[i])
         assert iters[i] == (it if st == 0 else -it)
