@@ -279,6 +279,14 @@ def test_gpu_finer_fit_all_packings(hs, dt, cdt, gpu_ctx):
         v = np.clip(v0[i] + np.cumsum(rng.normal(0, 1.5, hs)), 0, 30)
         seq[i] = rng.uniform(0, 100) + np.concatenate([[0.0], np.cumsum(v[1:] * cdt)])
     out, out_len, iters = gpu_ctx.finer_fit_batch(p, dt, cdt, seq, lens, v0, a0)
+    # the same batch with before/after-car position bounds (8 constraint rows per lane)
+    bac = np.stack([seq[:, 0] - rng.uniform(20, 60, N), rng.uniform(5, 12, N), seq[:, 0] + rng.uniform(30, 80, N), rng.uniform(10, 20, N)], axis=1)
+    bac[::5, 0] = -np.inf; bac[1::7, 2] = np.inf
+    out_b, out_len_b, iters_b = gpu_ctx.finer_fit_batch(p, dt, cdt, seq, lens, v0, a0, bac)
+    for i in range(N):
+        xb, itb, stb = ff.finer_fit(seq[i, :lens[i]], dt, cdt, v0[i], a0[i], S, bac[i])
+        assert out_len_b[i] == len(xb) and np.array_equal(out_b[i, :len(xb)], xb, equal_nan=True), ("bac", i, lens[i])
+        assert iters_b[i] == (itb if stb == 0 else -itb)
     for i in range(N):
         x, it, st = ff.finer_fit(seq[i, :lens[i]], dt, cdt, v0[i], a0[i], S)
         # (an infeasible little QP -- contradictory acceleration and jerk rows for a 2-sample path -- diverges to NaN in
