@@ -413,3 +413,30 @@ def test_band_cap_never_changes_results(cap, restore_settings, monkeypatch):
         res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
         _check(res, g, g["t_values"].size)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("STMPC_FUZZ_BIG_SEEDS", "4")))))
+def test_random_parameter_sets_large_batches(seed, restore_settings):
+    """Random wide-fan parameter sets at batch sizes where task splitting, the side launch and checkpoint/resume are all
+    active (more than two tasks per persistent workgroup)."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    rng = np.random.default_rng(7000 + seed)
+    over = _random_overrides(rng)
+    # force a wide fan-out (bounded search on) and a lattice big enough to overflow the first window now and then
+    over.update(S_DISCRETIZATION=0.05, T_DISCRETIZATION=0.3, MAX_POSITIVE_ACCELERATION=float(rng.uniform(4.0, 6.0)),
+                MAXIMUM_POSITIVE_JERK=35.0, MINIMUM_NEGATIVE_JERK=-35.0, FUTURE_S=float(rng.choice([200.0, 360.0])))
+    H = int(rng.integers(12, 41))
+    over["FUTURE_T"] = round((H - 1) * 0.3, 6)
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(over)
+    p = _capi.Params.from_settings(pkg.Settings)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    n = int(rng.integers(2100, 2600))
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=800 + seed, vary_k=True, dt=p.dt)
+    ctx = _capi.Context(0)
+    res = st.solve_arrays(ego, kc, ox, ov, p, ctx)
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=32)
+    _check(res, ref, _capi.num_t(p))
+    ctx.close()
