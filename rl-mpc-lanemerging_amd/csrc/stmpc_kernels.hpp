@@ -20,6 +20,11 @@
 //               bound and evaluates only candidates that can stay within it.  An episode whose live
 //               span exceeds W is queued, with its bound, for a tier with a larger window (LDS up to
 //               8192 cells, else HBM scratch; same code).
+//               Scheduling: the first launch hands out the bounding and the exact pass
+//               of an episode as separate tasks; the launch of the second window runs alongside it on a
+//               side stream and consumes the overflow queue as it fills; an exact pass that cannot build a
+//               layer in the first window checkpoints the finished layer and is continued, not restarted,
+//               in the second.
 //
 // Everything is fp64 and compiled with -ffp-contract=off: one IEEE op per reference op.
 #pragma once
@@ -449,8 +454,11 @@ enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 //   cost less, so none of them was cut, and any cut node could only offer candidates above the bound.
 //   With ubits = +inf bits this is the full layered DP.
 // PASS_BOUND: cheap search for an upper bound of the terminal cost: expands only nodes within `band` of
-//   the cheapest node of their layer and (hardsoft) treats cells closer than min_allowed to a vehicle as
-//   blocked; no back-pointers, no tie repair.  Any complete path it finds is a valid bound.
+//   the cheapest node of their layer (the band narrows when a layer expands more than band_cap nodes) and
+//   (hardsoft) treats cells closer than min_allowed to a vehicle as blocked; no back-pointers, no tie repair;
+//   instead of overflowing the window it drops a layer's lowest sources.  Any complete path it finds is a
+//   valid bound (ties between equal offers are broken by arrival, so its node counts may vary from run to run;
+//   the exact pass does not depend on them).
 //
 // Storage per lattice cell (circular, slot = cell & (W-1)):
 //   cost[]  u64  fp64 bits of the accumulated cost of the node, +inf bits = not reached
