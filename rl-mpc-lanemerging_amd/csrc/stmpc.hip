@@ -447,6 +447,11 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // (j_w * j_max^2 ~ 12 k on the benchmark lattice): a band that admits those steps keeps everything, and single
     // episodes then take several times longer (measured cliff at 44x the nominal band; 32x is used)
     a.band2_mult = c->band2_mult > 0 ? c->band2_mult : (c->band_cap > 0 && c->band_override <= 0 ? 4.0 : 5.0);
+    if (c->band2_mult <= 0 && c->band_cap > 0) {
+        const double dv = fmax(dp.v_des, dp.v_max - dp.v_des), da = fmax(fabs(dp.a_min), fabs(dp.a_max)), dj = fmax(fabs(dp.j_min), fabs(dp.j_max));
+        const double step_max = dp.v_w * dv * dv + dp.a_w * da * da + dp.j_w * dj * dj;      // dearest single step, penalties aside
+        if (step_max > 0 && a.band * a.band2_mult > 0.7 * step_max) a.band2_mult = fmax(1.0, 0.7 * step_max / a.band);
+    }
     a.band_cap = c->band_cap;
     a.force_general = c->force_general ? 1 : 0;
     a.ckpt = resume ? c->ckpt.as<unsigned char>() : nullptr; a.ckpt_stride = ckpt_stride; a.resume_t = resume_t;
