@@ -1,0 +1,132 @@
+/* lab.c -- offline node-count laboratory for bounding strategies (TEST/ANALYSIS INFRASTRUCTURE ONLY).
+ * Includes the oracle and adds a generic layered pass whose expansion set is configurable.  Nothing in the product
+ * includes or links this file; it is driven by oracle/analysis/lab.py on the build host to choose pre-pass designs
+ * before they are ported to the HIP kernel. */
+#include "../st_oracle.c"
+
+typedef struct { double key; int s; } lab_ent;
+static int lab_cmp(const void *a, const void *b) { double x = ((const lab_ent *)a)->key, y = ((const lab_ent *)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
+
+typedef struct {
+    double U;          /* expand only nodes with g <= U */
+    int beamK;         /* > 0: at most K nodes per layer (smallest key) */
+    double band;       /* > 0: only nodes with key <= min key + band */
+    int hmode;         /* 0: key = g;  1: key = g + kh[t] * (v_des - v)^2 */
+    double hscale;     /* multiplier of the heuristic */
+    int hardsoft;      /* 1: cells closer than min_allowed are blocked */
+    int stride;        /* > 1: only target cells with n % stride == 0 (last layer: all) */
+    int cap;           /* > 0 with band > 0: the band adapts to keep ~cap nodes per layer (kernel's rule) */
+    int twin;          /* > 0: target window cells of a single-wave beam pass: lowest sources whose targets do not fit are dropped */
+    int filt;          /* 1: count only candidate edges whose quadratic part can stay within U (exact-pass filter emulation) */
+} lab_cfg;
+
+typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; } lab_out;
+
+int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_values, int S, const double *t_values, int H,
+             double v0, double a0, const double *distances, double d_w, double v_w, double a_w, double j_w, double v_des,
+             double v_max, double a_min, double a_max, double j_min, double j_max, double min_allowed, int *path_idx, lab_out *out)
+{
+    double delta_s = s_values[1] - s_values[0], delta_t = t_values[1] - t_values[0], start_s = s_values[0];
+    double dt3 = orc_pow(delta_t, 3.0);
+    double est_prev = start_s - v0 * delta_t, est_second = est_prev - delta_t * (v0 - a0 * delta_t);
+    int32_t *previous = (int32_t *)malloc((size_t)H * S * sizeof(int32_t));
+    double *cc = (double *)malloc(sizeof(double) * S * 6);
+    double *cur_c = cc, *nxt_c = cc + S, *cur_p1 = cc + 2 * S, *nxt_p1 = cc + 3 * S, *cur_p2 = cc + 4 * S, *nxt_p2 = cc + 5 * S;
+    lab_ent *ents = (lab_ent *)malloc(sizeof(lab_ent) * S);
+    for (int i = 0; i < S; i++) cur_c[i] = INFINITY;
+    cur_c[0] = 0.0; cur_p1[0] = est_prev; cur_p2[0] = est_second;
+    int lo_w = 0, hi_w = 1, best_t = 0, best_s = 0; double best_cost = 0.0;
+    long long nodes = 0, edges = 0, maxspan = 0, maxlayer = 0;
+    memset(out, 0, sizeof *out);
+    const double U = cfg->U;
+    double bandt = cfg->band; long long rounds64 = 0;
+    const double lam = sqrt(v_w / (a_w > 0 ? a_w : 1.0)), Jc = sqrt(v_w * a_w) / delta_t;
+    for (int t = 0; t < H - 1; t++) {
+        int nlo = S, nhi = 0;
+        /* select the expansion set */
+        int cnt = 0; double kmin = INFINITY;
+        const double Trem = (double)(H - 1 - t) * delta_t;
+        const double kh = cfg->hmode ? cfg->hscale * Jc * tanh(lam * Trem) : 0.0;
+        for (int s = lo_w; s < hi_w; s++) {
+            double C = cur_c[s];
+            if (!(C < INFINITY) || C > U) continue;
+            double key = C;
+            if (cfg->hmode) { double v = (s_values[s] - cur_p1[s]) / delta_t; double D = v_des - v; key = C + kh * D * D; }
+            ents[cnt].key = key; ents[cnt].s = s; cnt++;
+            if (key < kmin) kmin = key;
+        }
+        { for (int i = 0; i < cnt; i++) { if (ents[i].key <= kmin * 1.003) out->flat3++; if (ents[i].key <= kmin * 1.01) out->flat10++; if (ents[i].key <= kmin * 1.03) out->flat30++; } }
+        if (cfg->band > 0) { int m = 0; for (int i = 0; i < cnt; i++) if (ents[i].key <= kmin + bandt) ents[m++] = ents[i]; cnt = m;
+            if (cfg->cap > 0 && cnt > 0) { double f = (double)cfg->cap / (double)cnt; bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > cfg->band ? cfg->band : (bandt < 0.05 * cfg->band ? 0.05 * cfg->band : bandt); } }
+        if (cfg->beamK > 0 && cnt > cfg->beamK) { qsort(ents, cnt, sizeof(lab_ent), lab_cmp); cnt = cfg->beamK; }
+        /* restore ascending-s order so ties resolve like the reference */
+        if (cfg->beamK > 0) { for (int i = 1; i < cnt; i++) { lab_ent e = ents[i]; int j = i - 1; while (j >= 0 && ents[j].s > e.s) { ents[j + 1] = ents[j]; j--; } ents[j + 1] = e; } }
+        if (cnt == 0) break;
+        if (cnt > maxlayer) maxlayer = cnt;
+        rounds64 += (cnt + 63) / 64;
+        out->per_layer[t] = cnt;
+        for (int i = lo_w > 0 ? lo_w : 0; i < S; i++) nxt_c[i] = INFINITY;
+        int32_t *prev_n = previous + (size_t)(t + 1) * S;
+        const int last = (t + 1 == H - 1);
+        int q0 = 0;
+        {   /* span of this layer's targets; a single-wave pass with a target window drops the lowest sources that do not fit */
+            int tlo = S, thi = 0;
+            for (int q = cnt - 1; q >= 0; q--) {
+                int s = ents[q].s; double mn, mx; int lo, hi;
+                orc_next_s_range(s_values[s], cur_p1[s], cur_p2[s], delta_t, j_min, j_max, a_min, a_max, v_max, &mn, &mx);
+                orc_range_indices(start_s, delta_s, mn, mx, &lo, &hi);
+                if (hi > S) hi = S;
+                if (hi <= lo) continue;
+                int nlo2 = lo < tlo ? lo : tlo, nhi2 = hi > thi ? hi : thi;
+                if (cfg->twin > 0 && nhi2 - nlo2 > cfg->twin) { q0 = q + 1; out->tspan_over++; break; }
+                tlo = nlo2; thi = nhi2;
+            }
+            if (thi - tlo > out->tspan) out->tspan = thi - tlo;
+        }
+        for (int q = q0; q < cnt; q++) {
+            int s = ents[q].s; double C = cur_c[s];
+            nodes++;
+            double sv = s_values[s], mn, mx; int lo, hi;
+            orc_next_s_range(sv, cur_p1[s], cur_p2[s], delta_t, j_min, j_max, a_min, a_max, v_max, &mn, &mx);
+            orc_range_indices(start_s, delta_s, mn, mx, &lo, &hi);
+            for (int n = lo; n < hi; n++) {
+                if (n >= S) break;
+                size_t nat = (size_t)(t + 1) * S + n;
+                if (obstacles[nat]) continue;
+                if (cfg->stride > 1 && !last && (n % cfg->stride)) continue;
+                if (cfg->hardsoft && distances[nat] < min_allowed) continue;
+                if (cfg->filt && U < 1e300) {
+                    double sn = s_values[n];
+                    double v = (sn - sv) / delta_t, a = (sn - 2 * sv + cur_p1[s]) / (delta_t * delta_t), j = (sn - 3 * sv + 3 * cur_p1[s] - cur_p2[s]) / dt3;
+                    double q_ = v_w * (v - v_des) * (v - v_des) + a_w * a * a + j_w * j * j;
+                    if (C + q_ > U) continue;
+                }
+                double c = C + orc_cost_with_jerk(s_values[n], sv, cur_p1[s], cur_p2[s], delta_t, dt3, distances[nat], min_allowed, v_w, v_des, a_w, j_w, d_w);
+                edges++;
+                if (c < nxt_c[n]) {
+                    nxt_c[n] = c; prev_n[n] = s; nxt_p1[n] = sv; nxt_p2[n] = cur_p1[s];
+                    if (n < nlo) nlo = n;
+                    if (n + 1 > nhi) nhi = n + 1;
+                }
+            }
+        }
+        if (nlo >= nhi) break;
+        { int span = nhi - ents[0].s; if (span > maxspan) maxspan = span; }
+        double bc = INFINITY; int bs = -1;
+        for (int n = nlo; n < nhi; n++) if (nxt_c[n] < bc) { bc = nxt_c[n]; bs = n; }
+        best_t = t + 1; best_s = bs; best_cost = bc;
+        double *tmp;
+        tmp = cur_c; cur_c = nxt_c; nxt_c = tmp; tmp = cur_p1; cur_p1 = nxt_p1; nxt_p1 = tmp; tmp = cur_p2; cur_p2 = nxt_p2; nxt_p2 = tmp;
+        lo_w = nlo; hi_w = nhi;
+    }
+    if (path_idx) {
+        int bs = best_s;
+        for (int t = 0; t < H; t++) path_idx[t] = -1;
+        for (int t = best_t; t > 0; t--) { path_idx[t] = bs; bs = previous[(size_t)t * S + bs]; }
+        path_idx[0] = bs;
+    }
+    out->nodes = nodes; out->edges = edges; out->maxspan = maxspan; out->maxlayer = maxlayer; out->rounds64 = rounds64; out->best_t = best_t; out->cost = best_cost;
+    out->complete = (best_t == H - 1) && !(best_cost > U);   /* the kernel's exact pass only accepts terminals within the bound */
+    free(previous); free(cc); free(ents);
+    return 0;
+}
