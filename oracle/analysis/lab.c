@@ -56,8 +56,30 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             if (key < kmin) kmin = key;
         }
         { for (int i = 0; i < cnt; i++) { if (ents[i].key <= kmin * 1.003) out->flat3++; if (ents[i].key <= kmin * 1.01) out->flat10++; if (ents[i].key <= kmin * 1.03) out->flat30++; } }
+        if (cfg->band > 0 && cfg->hmode == 3) {
+            /* mixed band selection as the kernel can do it in one scan: f within its band OR g within its band; each band is
+             * steered towards cap/2 nodes per layer */
+            static __thread double bandf, bandg; if (t == 0) { bandf = cfg->band; bandg = cfg->band; }
+            double gmin = INFINITY; for (int i = 0; i < cnt; i++) { double g_ = cur_c[ents[i].s]; if (g_ < gmin) gmin = g_; }
+            int m = 0, nf = 0, ng = 0;
+            for (int i = 0; i < cnt; i++) { int byf = ents[i].key <= kmin + bandf, byg = cur_c[ents[i].s] <= gmin + bandg; nf += byf; ng += byg; if (byf || byg) ents[m++] = ents[i]; }
+            cnt = m;
+            if (cfg->cap > 0) {
+                double half = 0.5 * cfg->cap, f;
+                if (nf > 0) { f = half / nf; bandf *= (f < 1.0 ? f : sqrt(f)); bandf = bandf > cfg->band ? cfg->band : (bandf < 0.02 * cfg->band ? 0.02 * cfg->band : bandf); }
+                if (ng > 0) { f = half / ng; bandg *= (f < 1.0 ? f : sqrt(f)); bandg = bandg > cfg->band ? cfg->band : (bandg < 0.02 * cfg->band ? 0.02 * cfg->band : bandg); }
+            }
+        } else
         if (cfg->band > 0) { int m = 0; for (int i = 0; i < cnt; i++) if (ents[i].key <= kmin + bandt) ents[m++] = ents[i]; cnt = m;
             if (cfg->cap > 0 && cnt > 0) { double f = (double)cfg->cap / (double)cnt; bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > cfg->band ? cfg->band : (bandt < 0.05 * cfg->band ? 0.05 * cfg->band : bandt); } }
+        if (cfg->beamK > 0 && cnt > cfg->beamK && cfg->hmode == 3) {
+            /* mixed beam: K/2 smallest by f = g + h, then K/2 smallest by g among the rest */
+            qsort(ents, cnt, sizeof(lab_ent), lab_cmp);
+            int kf = cfg->beamK / 2, m = kf;
+            for (int i = kf; i < cnt; i++) ents[i].key = cur_c[ents[i].s];
+            qsort(ents + kf, cnt - kf, sizeof(lab_ent), lab_cmp);
+            cnt = cfg->beamK; (void)m;
+        } else
         if (cfg->beamK > 0 && cnt > cfg->beamK) { qsort(ents, cnt, sizeof(lab_ent), lab_cmp); cnt = cfg->beamK; }
         /* restore ascending-s order so ties resolve like the reference */
         if (cfg->beamK > 0) { for (int i = 1; i < cnt; i++) { lab_ent e = ents[i]; int j = i - 1; while (j >= 0 && ents[j].s > e.s) { ents[j + 1] = ents[j]; j--; } ents[j + 1] = e; } }

@@ -131,6 +131,11 @@ for K in (48, 64):
     for tw in (384, 448, 512, 640):
         _add("cK%dw%d_m1.003" % (K, tw), [dict(K=K, hs=1, hmode=1, twin=tw)] + R1A, 1.003)
 
+for K1, K2 in ((64, 128), (128, 256), (256, 256), (128, 128), (192, 256), (64, 256)):
+    for mg in (1.002, 1.003, 1.005):
+        _add("s%d_%d_m%.3f" % (K1, K2, mg), [dict(K=K1, hs=0, hmode=1), dict(K=K2, hs=1, hmode=1)], mg, "soft")
+_add("s128_256_r1_m1.003", [dict(K=128, hs=0, hmode=1), dict(K=256, hs=1, hmode=1), dict(band=8 * BAND, cap=300, hs=1)], 1.003, "soft")
+
 def run_spec(spec, grid, v0, a0, H):
     attempts, margin, combine = spec
     pn = pe = pr = 0; U = INF
@@ -140,6 +145,7 @@ def run_spec(spec, grid, v0, a0, H):
         if o.complete:
             U = min(U, o.cost)
             if combine == "first": break
+            if combine == "soft" and U < 1e5: break      # a path free of min-distance penalties: accept
     return pn, pe, pr, (U * margin if U < INF else U)
 for _nm, _sp in SPECS.items():
     VARIANTS[_nm] = (lambda sp: lambda grid, v0, a0, H: run_spec(sp, grid, v0, a0, H))(_sp)

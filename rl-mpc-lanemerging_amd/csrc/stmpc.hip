@@ -69,7 +69,7 @@ struct stmpc_ctx {
     DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, proxy, order, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
-    DevBuf ckpt, resume_t;
+    DevBuf ckpt, resume_t, phase_prof;
     DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
@@ -99,6 +99,7 @@ struct stmpc_ctx {
     bool last_has_hbm = true;
     // STMPC_OVERLAP=0/1: start the second LDS tier on its own stream while the first is still running (see k_solve)
     bool resume = true;            // STMPC_RESUME=0/1: the wider window continues a checkpointed exact pass instead of starting over
+    int gsh_max = 4;               // STMPC_GSH=0..4: lanes per source of sparse layers, log2 (0 = one lane per source)
     bool split = true;             // STMPC_SPLIT=0/1: bounding and exact pass of an episode are separate tasks of the first launch (-4 % at N=4096)
     int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
     hipStream_t aux_stream = nullptr;
@@ -192,6 +193,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND_CAP")) { int v = atoi(w); if (v >= 0) c->band_cap = v; }
     if (const char *w = getenv("STMPC_SPLIT")) c->split = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_GSH")) { int v = atoi(w); if (v >= 0 && v <= 4) c->gsh_max = v; }
     if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
@@ -218,7 +220,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
-                     &c->ckpt, &c->resume_t, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
+                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -454,6 +456,12 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     }
     a.band_cap = c->band_cap;
     a.force_general = c->force_general ? 1 : 0;
+    a.gsh_max = c->gsh_max;
+#ifdef STMPC_PHASE_PROF
+    if ((rc = c->phase_prof.ensure(2 * STMPC_NPH * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipMemsetAsync(c->phase_prof.p, 0, 2 * STMPC_NPH * sizeof(unsigned long long), st));
+    a.phase_prof = c->phase_prof.as<unsigned long long>();
+#endif
     a.ckpt = resume ? c->ckpt.as<unsigned char>() : nullptr; a.ckpt_stride = ckpt_stride; a.resume_t = resume_t;
     a.W0 = tierW[0];
     a.maxshift = (int)ceil(dp.v_max * dp.dt / dp.ds) + 2 + 66;     // st_cy.pyx:65-93: v <= v_max; + interval rounding to 64-cell blocks
@@ -549,6 +557,14 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         float ms_all = 0.f, ms_dp = 0.f;
         HIPCHK(hipEventElapsedTime(&ms_all, c->ev0, c->ev3));
         HIPCHK(hipEventElapsedTime(&ms_dp, c->ev1, c->ev2));
+#ifdef STMPC_PHASE_PROF
+        if (const char *f = getenv("STMPC_PHASE_DUMP")) {
+            unsigned long long pp[2 * STMPC_NPH];
+            HIPCHK(hipMemcpy(pp, c->phase_prof.p, sizeof pp, hipMemcpyDeviceToHost));
+            FILE *fp = fopen(f, "w");
+            if (fp) { for (int m = 0; m < 2; ++m) { for (int k = 0; k < STMPC_NPH; ++k) fprintf(fp, "%llu ", pp[m * STMPC_NPH + k]); fprintf(fp, "\n"); } fclose(fp); }
+        }
+#endif
         c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window
         c->stats.hbm_tier = (c->last_has_hbm && c->last_nt >= 2) ? cnt[4 * (c->last_nt - 1)] : 0;
         c->stats.fast_path = c->stats.episodes - cnt[4];
@@ -668,7 +684,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     memset(&a, 0, sizeof a);
     a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.PW = Wg; a.last_tier = 1;
     a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
-    a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0;
+    a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0; a.gsh_max = c->gsh_max;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();
     a.s_sequence = c->s_misc3.as<double>();
     hipLaunchKernelGGL((k_solve<false, true, false, 0, 16, true>), dim3(1), dim3(256), ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16, nullptr, a);

@@ -36,6 +36,20 @@ typedef unsigned short u16;
 
 #define STMPC_MAXH 64
 
+// Phase profile of the lattice pass (analysis builds only, -DSTMPC_PHASE_PROF): thread 0 of every workgroup accumulates
+// the shader clock between the marks below (waits at a barrier count towards the phase that ends with it) and adds
+// the totals to SolveArgs::phase_prof[pass][phase] when the pass ends.  Compiled out of the product build.
+#ifdef STMPC_PHASE_PROF
+#define STMPC_NPH 16
+#define STMPC_PH_DECL unsigned long long ph_acc_[STMPC_NPH] = {0}; unsigned long long ph_t_ = __builtin_readcyclecounter();
+#define STMPC_PH(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc_[k] += n_ - ph_t_; ph_t_ = n_; } } while (0)
+#define STMPC_PH_FLUSH(mode) do { if (threadIdx.x == 0 && a.phase_prof) for (int k_ = 0; k_ < STMPC_NPH; ++k_) atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + k_], ph_acc_[k_]); } while (0)
+#else
+#define STMPC_PH_DECL
+#define STMPC_PH(k) do { } while (0)
+#define STMPC_PH_FLUSH(mode) do { } while (0)
+#endif
+
 namespace stmpc {
 
 static constexpr u64 INF_BITS = 0x7FF0000000000000ull;
@@ -372,6 +386,8 @@ struct SolveArgs {
     const u16 *bp0;        // tier >= 1: tier 0's per-episode back-pointers (row stride W0) or null
     int W0;                // first window (cells)
     int maxshift;          // upper bound of (target cell - source cell) + rounding slack of the interval bookkeeping
+    unsigned long long *phase_prof;   // analysis builds: [2][16] clock totals per pass and phase, else null
+    int gsh_max;           // a sparse layer spreads a source over up to 2^gsh_max lanes (dp_pass)
     int split;             // tier 0 hands out 2N tasks: the bounding pre-passes of all episodes, then their exact passes
     int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
@@ -540,6 +556,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     nk.invK = 1.0 / (nk.kv + nk.ka + nk.kj);
     nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
 
+    STMPC_PH_DECL
     M::barrier();                       // previous users of the arrays are done
     int wlo = 0, whi = 1;
     if (RES == 2 && t_start > 0) {      // continue a pass checkpointed by the first window (see SolveArgs::ckpt)
@@ -555,6 +572,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     int maxspan = 0;
 
     const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
+    STMPC_PH(0);                        // 0: pass set-up
     for (int t = t_start; t <= last_src_layer; ++t) {
         const bool relax = t < H - 1;
         int ilo = 0, ihi = 0;
@@ -661,6 +679,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // 64-cell chunks, chunk j = cells [top0-64(j+1), top0-64j); wave w owns the contiguous chunks
         // [w*cpw, (w+1)*cpw) and writes its cells into its own segment of list[] (capacity cpw*64), so one pass
         // and one barrier suffice; a global list index is mapped to (segment, offset) with the segment counts.
+        STMPC_PH(1);                    // 1: layer set-up (threshold, vehicle rows)
         const int top0 = (whi + 63) & ~63;
         const int nch = (top0 - (wlo & ~63)) >> 6;
         const int cpw = (nch + NW - 1) / NW;
@@ -690,6 +709,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
         }
         M::barrier();        // S1
+        STMPC_PH(2);                    // 2: scan + S1
         int segbase[STMPC_MAXWAVES + 1];
         segbase[0] = 0;
 #pragma unroll
@@ -734,11 +754,20 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
         }
 
-        // ---- expand: rounds of 64*NW listed sources, highest cells first
+        STMPC_PH(3);                    // 3: list boundaries, layer's best node, checkpoint test
+        // ---- expand: rounds of listed sources, highest cells first.  A sparse layer spreads each source over G = 2^gsh
+        // adjacent lanes (lane `sub` of a group takes the candidates sub, sub + G, ...), so that a layer with few nodes
+        // still fills the workgroup's lanes: the candidate loop runs ceil(fan / G) slots instead of fan.  All lanes of a
+        // group load the same source (LDS broadcast) and derive the same range; which lane evaluates a candidate
+        // does not matter to the staged minimum below.
+        int gsh = 0;
+        if (relax) { while (gsh < a.gsh_max && (nlist << (gsh + 1)) <= per) ++gsh; }
+        const int sub = tid & ((1 << gsh) - 1);
         for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
-            rstep = per;
-            const bool inlist = r0 + tid < nlist;
-            const int i = inlist ? list_at(r0 + tid) : 0;
+            rstep = per >> gsh;
+            const int srcidx = r0 + (tid >> gsh);
+            const bool inlist = srcidx < nlist;
+            const int i = inlist ? list_at(srcidx) : 0;
             const int smin = list_at(nlist - 1);                 // lowest source of the layer
             u64 cb = INF_BITS;
             unsigned h = 0u;
@@ -827,12 +856,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 }
             }
             if constexpr (MODE == PASS_EXACT) { if (__ballot(cut_l) && lane == 0) atomicOr(&sh.flags, 1); }
+            STMPC_PH(4);                // 4: source load, range, candidate filter
             if (relax) {
                 const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
                 const int fan_w = wave_max_i(hi - lo);
                 if (lane == 0) { sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w; }
             }
             M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
+            STMPC_PH(5);                // 5: wave reductions + B1
             // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer.
             int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0;
             if (relax) {
@@ -843,10 +874,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     if (w > 0 && h2 > l2 && (((h2 + 63) & ~63) - (l2 & ~63)) > PW) break;
                     clo = l2; chi = h2; fan = f_ > fan ? f_ : fan; kw = w + 1;
                 }
-                rstep = 64 * kw;
+                rstep = (64 * kw) >> gsh;
             }
             const bool act = inlist && wave < kw;
-            if constexpr (MODE == PASS_EXACT) { if (act && t > 0) bp[(size_t)t * W + (i & WM)] = (u16)pr; }
+            if constexpr (MODE == PASS_EXACT) { if (act && t > 0 && sub == 0) bp[(size_t)t * W + (i & WM)] = (u16)pr; }
             if (!act) { lo = 0; hi = 0; }
             if (!relax) continue;
             const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
@@ -869,6 +900,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 else return 1;
             }
             if (chi - clo > PW) return 1;                                    // 64 sources' targets exceed the penalty buffer
+            STMPC_PH(6);                // 6: round geometry (interval bookkeeping)
             if (clo < ilo) init_cells(clo, ilo);
             if (chi > ihi) init_cells(ihi, chi);
             ilo = nlo2; ihi = nhi2;
@@ -879,24 +911,26 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (need_hi > pv_hi) repen(pv_hi, need_hi);
             }
             M::barrier();     // B2: next-layer cells of this round are initialised
+            STMPC_PH(7);                // 7: cell initialisation (penalties) + B2
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
-            for (int cbase = 0; cbase < fan; cbase += FANMAX) {
+            auto cand = [&](int slot) -> int { return lo + sub + (slot << gsh); };      // cell of this lane's slot-th candidate
+            for (int cbase = 0; (cbase << gsh) < fan; cbase += FANMAX) {
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
                 constexpr int UB = (FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX);   // small batches: slots beyond a wave's widest range are skipped
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
-                    if (__ballot(lo + cbase + ub < hi)) {
+                    if (__ballot(cand(cbase + ub) < hi)) {
                         // branch-free: lanes without a candidate at this offset compute on whatever the slot holds and
                         // then offer ~0, which a min never takes
                         double pn[UB];
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) pn[u] = M::ldf(&pen[(lo + cbase + ub + u) & PWM]);
+                        for (int u = 0; u < UB; ++u) pn[u] = M::ldf(&pen[cand(cbase + ub + u) & PWM]);
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            const int n = lo + cbase + ub + u;
+                            const int n = cand(cbase + ub + u);
                             const double sn = sval(n);
                             // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
                             const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
@@ -911,7 +945,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            const u64 old = M::min64(&cost[(lo + cbase + ub + u) & WM], tb[ub + u]);
+                            const u64 old = M::min64(&cost[cand(cbase + ub + u) & WM], tb[ub + u]);
                             if (old > tb[ub + u]) improved |= 1u << (ub + u);
                             else if (old == tb[ub + u]) tied |= 1u << (ub + u);
                         }
@@ -921,6 +955,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     }
                 }
                 M::barrier();     // B3: every min of this round is in
+                STMPC_PH(8);            // 8: stage A (candidate costs, atomic minima) + B3
                 // stage B: the unique first setter of a cell's final value records the predecessor.
                 // Read-backs are issued in groups of 4 (unconditionally) so their LDS latencies overlap.
 #pragma unroll
@@ -928,25 +963,27 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     if (__ballot(((improved >> ub) & 0xFu) != 0u)) {
                         u64 cur[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(&cost[(lo + cbase + ub + u) & WM]);
+                        for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(&cost[cand(cbase + ub + u) & WM]);
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(&hist[(lo + cbase + ub + u) & WM], key); }
+                            if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(&hist[cand(cbase + ub + u) & WM], key); }
                     }
                 }
                 M::barrier();     // B4
+                STMPC_PH(9);            // 9: stage B (first setter writes the predecessor) + B4
                 if constexpr (MODE == PASS_EXACT) {
                     // stage C: equal total cost -> the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
                     if (__ballot(tied != 0u)) {
 #pragma unroll
                         for (int u = 0; u < FANMAX; ++u) {
                             if ((tied >> u) & 1u) {
-                                const int sl = (lo + cbase + u) & WM;
+                                const int sl = cand(cbase + u) & WM;
                                 if (M::ld64(&cost[sl]) == tb[u]) M::min32(&hist[sl], key);
                             }
                         }
                     }
                 }
+                STMPC_PH(10);           // 10: stage C (tie repair)
             }
             if (last_round) break;
         }
@@ -963,10 +1000,12 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             lmin = mt;
             if (mt < INF_BITS) { out.best_t = t + 1; out.best_bits = mt; }
         }
+        STMPC_PH(11);                   // 11: end of layer
         if (!relax) break;
         if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
     }
     M::barrier();
+    STMPC_PH_FLUSH(MODE);
     out.pruned = (sh.flags & 1) != 0;
     out.nodes = total_nodes;
     out.maxspan = maxspan;

@@ -1,5 +1,8 @@
-import subprocess, sys
-p='rl-mpc-lanemerging_amd/csrc/stmpc_kernels.hpp'
+import os, shutil, subprocess, sys
+TMP='/tmp/stmpc_times_src'
+shutil.rmtree(TMP, ignore_errors=True)
+shutil.copytree('rl-mpc-lanemerging_amd/csrc', TMP)
+p=TMP+'/stmpc_kernels.hpp'
 s=open(p).read()
 s=s.replace("    int last_tier;         // overflow here is an internal error","    int last_tier;         // overflow here is an internal error\n    unsigned long long *dbg_t;   // [N][12]: (start, end, kind, block) x {tier-0 bounding task, tier-0 exact task, tier >= 1}")
 old="            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN, RES>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);\n"
@@ -12,11 +15,10 @@ old4="            if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (u
 assert old4 in s
 s=s.replace(old4, old4+"            if (tid == 0 && a.tier == 0) { a.dbg_t[(size_t)e * 16 + 12] = (unsigned long long)out.maxspan; a.dbg_t[(size_t)e * 16 + 13] = (unsigned long long)bn; a.dbg_t[(size_t)e * 16 + 14] = (unsigned long long)(ubits != INF_BITS); }   // dbg span\n")
 open(p,'w').write(s)
-p='rl-mpc-lanemerging_amd/csrc/stmpc.hip'
+p=TMP+'/stmpc.hip'
 s=open(p).read()
 s=s.replace("    a.proxy = c->proxy.as<unsigned>();\n","    a.proxy = c->proxy.as<unsigned>();\n    if ((rc = c->s_misc1.ensure((size_t)N * 128))) return rc;\n    HIPCHK(hipMemsetAsync(c->s_misc1.p, 0, (size_t)N * 128, st));\n    a.dbg_t = c->s_misc1.as<unsigned long long>();\n",1)
 s=s.replace("        c->stats.fallback = cnt[4];                       // episodes","        if (const char *f = getenv(\"STMPC_DUMP_TIMES\")) {\n            std::vector<unsigned long long> tb((size_t)c->stats.episodes * 16);\n            HIPCHK(hipMemcpy(tb.data(), c->s_misc1.p, tb.size() * 8, hipMemcpyDeviceToHost));\n            FILE *fp = fopen(f, \"wb\"); fwrite(tb.data(), 8, tb.size(), fp); fclose(fp);\n        }\n        c->stats.fallback = cnt[4];                       // episodes",1)
 open(p,'w').write(s)
-r=subprocess.run("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -Iinclude rl-mpc-lanemerging_amd/csrc/stmpc.hip -o variants/libstmpc_times.so", shell=True)
-subprocess.run("git checkout rl-mpc-lanemerging_amd/csrc", shell=True)
+r=subprocess.run("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -Iinclude "+TMP+"/stmpc.hip -o variants/libstmpc_times.so", shell=True)
 sys.exit(r.returncode)
