@@ -14,7 +14,7 @@ os.environ["STMPC_PHASE_DUMP"] = out
 st.solve_arrays(ego, k, ox, ov, p, ctx)
 s = ctx.stats()
 a = np.loadtxt(out)
-names = ["setup", "layer-setup", "scan+S1", "list/best", "src+range+filter", "reduce+B1", "geometry", "init+B2", "stageA+B3", "stageB+B4", "stageC", "layer-end"]
+names = ["setup", "layer-setup", "scan+S1", "list/best", "src+range+filter", "reduce+B1", "geometry", "init+B2", "stageA-rest+B3", "stageB+B4", "stageC", "layer-end", "stageA-arith", "stageA-atomics"]
 print(out, "solve_ms %.3f nodes exact %d bound %d" % (s["solve_ms"], s["nodes_exact"], s["nodes_bound"]))
 for m, nm in enumerate(("EXACT", "BOUND")):
     tot = a[m].sum()
