@@ -13,6 +13,8 @@
  *   stmpc_predict_batch       <- HighwayState.predict_step_with_ego / predict_step_without_ego (prediction.py:22-105)
  *   stmpc_finer_fit_batch     <- st.finer_fit                        st.py:584-723 (QP via cvxopt.solvers.qp, st.py:16-17,722)
  *   stmpc_st_control_batch[_device] <- st.do_st_control              st.py:757-783 applied to N independent states
+ *   stmpc_rollout_step_device / stmpc_combined_decide_device <- dqn.RLAgent.do_combined_control  dqn.py:117-200 (the policy
+ *                                network stays the caller's; everything around it runs here)
  *   stmpc_ego_s               <- control.get_ego_s                   control.py:373-380
  *   stmpc_num_s / stmpc_num_t <- the np.arange sizes at st.py:31-32
  *
@@ -21,6 +23,14 @@
  * stmpc_last_error() returns a thread-local message for the last failure.
  * The library has no CPU fallback: without a HIP device every compute entry
  * returns STMPC_ENODEV.
+ *
+ * Concurrency: a context owns one set of scratch buffers, work counters and overflow queues; AT MOST ONE batched call may be
+ * in flight per context (calls on one stream are naturally ordered; calls on different streams, or from different host
+ * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only.
+ * Scratch: the wide-lattice solver keeps 2 bytes per lattice cell of the first window and time layer per episode for its
+ * back-pointers when it may continue an overflowing search in the next window (N * H * 2048 * 2 B: 0.66 GB for 4096 episodes at
+ * H = 40, released by stmpc_destroy); if that allocation fails the solver falls back to per-workgroup storage (restarting instead
+ * of continuing overflowing episodes).
  */
 #ifndef STMPC_H
 #define STMPC_H
@@ -168,13 +178,15 @@ int stmpc_build_grid(stmpc_ctx *ctx, const stmpc_params *p, const double *state5
  *   mode 0: predict_step_with_ego(selected_speed[i], dt, min_crash_distance)
  *   mode 1: predict_step_without_ego(dt, min_crash_distance)   (selected_speed ignored, may be NULL)
  * state layout as in stmpc_solve_batch but ego is [N][4] = x, y, v, a.  Outputs have the same
- * shapes; crashed [N] receives the crash flag.
+ * shapes; crashed [N] receives the crash flag; other_a_out [N][Kmax] (may be NULL) the new_other_accelerations
+ * of prediction.py:86-89,97 (the deceleration applied to a following vehicle, else 0) -- what the RL state vector reads
+ * (dqn.get_state_vector_from_base_state, dqn.py:400).
  */
 int stmpc_predict_batch(stmpc_ctx *ctx, const stmpc_params *p, int mode, int N, int Kmax,
                         const double *ego4, const int32_t *k_count, const double *other_x,
                         const double *other_v, const double *selected_speed, double dt,
                         double min_crash_distance, double *ego4_out, double *other_x_out,
-                        double *other_v_out, int32_t *crashed);
+                        double *other_v_out, int32_t *crashed, double *other_a_out);
 
 #define STMPC_QP_NMAX     64   /* max fine samples of st.finer_fit (one wavefront lane per sample) */
 #define STMPC_QP_MAXITERS 10   /* solvers.options['maxiters'] = 10, st.py:17 */
@@ -211,6 +223,49 @@ int stmpc_st_control_batch_device(stmpc_ctx *ctx, const stmpc_params *p, double 
                                   const double *d_ego, const int32_t *d_k_count, const double *d_other_x,
                                   const double *d_other_v, int32_t *d_path_idx, int32_t *d_best_t, double *d_cost,
                                   double *d_speed, double *d_fine, int32_t *d_fine_len, void *stream);
+
+/*
+ * Combined RL + ST controller, dqn.RLAgent.do_combined_control (dqn.py:117-200), for N independent states, DEVICE pointers.
+ * The policy network is the caller's: it proposes one jerk per live episode and rollout step (dqn.py:119,132).  Protocol per tick:
+ *   for step = 1 .. max(rollout_length, 1):
+ *       action[N] = policy(current state arrays)              (caller, on the device; step 1 uses first_action)
+ *       stmpc_rollout_step_device(.., step, ..)               speed from jerk (control.py:160-171), predict_step_with_ego with
+ *                                                             COMBINATION_MIN_DISTANCE (dqn.py:136), history / probe-state bookkeeping;
+ *                                                             episodes whose rollout ended (crash predicted, x > STOP_X) are left untouched
+ *   stmpc_combined_decide_device(..)                          feasibility probe of the rolled-out state (one batched solve), controller solve of
+ *                                                             the start state (lattice search + QP re-sampling), decision rules of dqn.py:144-200
+ * Outputs: takeover [N] (what the reference appends to takeover_history), reason [N] (0 policy kept, 1 crash predicted, 2 policy too fast,
+ * 3 probe rejects the rolled-out state, 4 ST path deemed better), speed [N] (the commanded speed: st.do_st_control's for reasons 1-3, the first
+ * re-sampled step for 4, control.get_ego_speed_from_jerk(first_action) for 0).  cur_* arrays are updated in place by the rollout steps;
+ * cur_oa [N][Kmax] (may be NULL) receives the other vehicles' accelerations for the policy's state vector.  The rollout history's
+ * s coordinates of predicted positions come from the device map of control.get_ego_s (squares as x*x where CPython calls pow).
+ */
+#define STMPC_ROLLOUT_LIMIT 63
+typedef struct stmpc_combined_cfg {
+    double tick_length;              /* Settings.TICK_LENGTH */
+    double stop_x;                   /* Settings.STOP_X */
+    int32_t rollout_length;          /* Settings.ROLLOUT_LENGTH */
+    int32_t st_test_rollouts;        /* Settings.ST_TEST_ROLLOUTS */
+    int32_t check_rollout_crash;     /* Settings.CHECK_ROLLOUT_CRASH */
+    int32_t limit_dqn_speed;         /* Settings.LIMIT_DQN_SPEED */
+    int32_t test_rollout_state;      /* Settings.TEST_ROLLOUT_STATE */
+    int32_t test_st_strictly_better; /* Settings.TEST_ST_STRICTLY_BETTER */
+    int32_t remember_last_choice;    /* Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED */
+} stmpc_combined_cfg;
+int stmpc_rollout_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_combined_cfg *cfg, int N, int Kmax, int step,
+                              const double *d_ego5_start, double *d_cur_ego4, const int32_t *d_k_count, double *d_cur_other_x,
+                              double *d_cur_other_v, double *d_cur_other_a, const double *d_action, void *stream);
+int stmpc_combined_decide_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_combined_cfg *cfg, int N, int Kmax,
+                                 const double *d_ego5_start, const int32_t *d_k_count, const double *d_other_x_start,
+                                 const double *d_other_v_start, const double *d_cur_ego4, const double *d_cur_other_x,
+                                 const double *d_cur_other_v, const double *d_first_action, const int32_t *d_last_choice_rl,
+                                 int32_t *d_takeover, int32_t *d_reason, double *d_speed, void *stream);
+/* Host copies of the context's rollout bookkeeping and intermediate results (synchronises; any pointer may be NULL):
+ * live, hist_len, crash_pred, have_test [N]; sel_speed [N]; rollout_s [N][rollout_length + 1]; test_ego4 [N][4], test_ox / test_ov [N][Kmax];
+ * probe_crash [N], st_speed [N], fine [N][STMPC_QP_NMAX], fine_len [N] (valid after stmpc_combined_decide_device). */
+int stmpc_combined_read_state(stmpc_ctx *ctx, int N, int32_t *live, int32_t *hist_len, int32_t *crash_pred, double *sel_speed,
+                              double *rollout_s, int32_t *have_test, double *test_ego4, double *test_ox, double *test_ov,
+                              int32_t *probe_crash, double *st_speed, double *fine, int32_t *fine_len);
 
 /* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
  * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b) HOST pointers. */

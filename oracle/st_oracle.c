@@ -57,6 +57,26 @@ typedef struct {
     long long cells;     /* distinct target cells reached */
 } orc_stats;
 
+/* Scratch memory.  A batch worker thread owns one arena that it resets before every episode, so that the large per-solve
+ * arrays (grids, back-pointers, label rows: ~4 MB at S = 7201, H = 40) are not mmap'ed and unmapped once per solve --
+ * with many threads that serialises on the process's address-space lock and was what the cpu_baseline measured.
+ * Outside a worker (single calls from the tests) the same macros fall through to malloc/free. */
+typedef struct { char *base; size_t cap, off; int active; } orc_arena;
+static __thread orc_arena orc_ws = {0, 0, 0, 0};
+static void *orc_alloc(size_t n, int zero)
+{
+    if (orc_ws.active) {
+        size_t at = (orc_ws.off + 63) & ~(size_t)63;
+        if (at + n <= orc_ws.cap) { orc_ws.off = at + n; void *q = orc_ws.base + at; if (zero) memset(q, 0, n); return q; }
+    }
+    return zero ? calloc(n, 1) : malloc(n);
+}
+static void orc_release(void *q)
+{
+    if (orc_ws.active && (char *)q >= orc_ws.base && (char *)q < orc_ws.base + orc_ws.cap) return;   /* arena memory: reset wholesale */
+    free(q);
+}
+
 /* libm pow through a volatile pointer: Python's float ** int and Cython's dt**3 are
  * runtime libm pow() calls (control.py:38, st_cy.pyx:49); gcc must not fold them. */
 static double (*volatile orc_pow)(double, double) = pow;
@@ -305,6 +325,20 @@ static void heap_push(orc_heap *h, orc_item it)
     }
     h->a[i] = it;
 }
+/* the heap's item array is kept per thread between solves of a batch worker (it grows to ~10 MB on the wide lattice) */
+static __thread orc_heap orc_heap_keep = {0, 0, 0};
+static orc_heap orc_heap_get(void)
+{
+    orc_heap h = {0, 0, 0};
+    if (orc_ws.active) { h = orc_heap_keep; h.n = 0; orc_heap_keep.a = NULL; orc_heap_keep.cap = 0; }
+    return h;
+}
+static void orc_heap_done(orc_heap *h)
+{
+    if (orc_ws.active) { orc_heap_keep = *h; orc_heap_keep.n = 0; }
+    else free(h->a);
+    h->a = NULL;
+}
 static orc_item heap_pop(orc_heap *h)
 {
     orc_item top = h->a[0];
@@ -334,11 +368,11 @@ int orc_solve_heap(const uint8_t *obstacles, const double *s_values, int S, cons
     double delta_t = t_values[1] - t_values[0];          /* :319 */
     double start_s = s_values[0];                        /* :320 */
     double dt3 = orc_pow(delta_t, 3.0);                  /* delta_t**3 :49 */
-    uint8_t *encountered = (uint8_t *)calloc((size_t)H * S, 1);          /* :323 */
-    int32_t *previous = (int32_t *)calloc((size_t)H * S, sizeof(int32_t)); /* :324 */
+    uint8_t *encountered = (uint8_t *)orc_alloc((size_t)H * S, 1);       /* :323 */
+    int32_t *previous = (int32_t *)orc_alloc((size_t)H * S * sizeof(int32_t), 1); /* :324 */
     double est_prev = start_s - v0 * delta_t;            /* :329 */
     double est_second = est_prev - delta_t * (v0 - a0 * delta_t); /* :330 */
-    orc_heap h = {0, 0, 0};
+    orc_heap h = orc_heap_get();
     orc_item first = {0.0, 0, 0, start_s, 0, est_prev, 0, est_second};   /* :342 */
     heap_push(&h, first);
     int best_last_s = 0, best_t = 0;                     /* :352-353 */
@@ -379,7 +413,7 @@ int orc_solve_heap(const uint8_t *obstacles, const double *s_values, int S, cons
     s_sequence[0] = s_values[bs]; path_idx[0] = bs;      /* :398 */
     *best_t_out = best_t; *cost_out = best_cost;
     if (stats) { stats->nodes = nodes; stats->edges = edges; stats->cells = 0; }
-    free(h.a); free(encountered); free(previous);
+    orc_heap_done(&h); orc_release(encountered); orc_release(previous);
     return 0;
 }
 
@@ -400,10 +434,10 @@ int orc_solve_layered(const uint8_t *obstacles, const double *s_values, int S, c
     double dt3 = orc_pow(delta_t, 3.0);
     double est_prev = start_s - v0 * delta_t;
     double est_second = est_prev - delta_t * (v0 - a0 * delta_t);
-    int32_t *previous = (int32_t *)malloc((size_t)H * S * sizeof(int32_t));
-    double *cc = (double *)malloc(sizeof(double) * S * 2);
-    double *p1 = (double *)malloc(sizeof(double) * S * 2);   /* history value s_{t-1} per node */
-    double *p2 = (double *)malloc(sizeof(double) * S * 2);   /* history value s_{t-2} per node */
+    int32_t *previous = (int32_t *)orc_alloc((size_t)H * S * sizeof(int32_t), 0);
+    double *cc = (double *)orc_alloc(sizeof(double) * S * 2, 0);
+    double *p1 = (double *)orc_alloc(sizeof(double) * S * 2, 0);   /* history value s_{t-1} per node */
+    double *p2 = (double *)orc_alloc(sizeof(double) * S * 2, 0);   /* history value s_{t-2} per node */
     double *cur_c = cc, *nxt_c = cc + S, *cur_p1 = p1, *nxt_p1 = p1 + S, *cur_p2 = p2, *nxt_p2 = p2 + S;
     for (int i = 0; i < S; i++) cur_c[i] = INFINITY;
     cur_c[0] = 0.0; cur_p1[0] = est_prev; cur_p2[0] = est_second;
@@ -455,7 +489,7 @@ int orc_solve_layered(const uint8_t *obstacles, const double *s_values, int S, c
     s_sequence[0] = s_values[bs]; path_idx[0] = bs;
     *best_t_out = best_t; *cost_out = best_cost;
     if (stats) { stats->nodes = nodes; stats->edges = edges; stats->cells = cells; }
-    free(previous); free(cc); free(p1); free(p2);
+    orc_release(previous); orc_release(cc); orc_release(p1); orc_release(p2);
     return 0;
 }
 
@@ -490,10 +524,10 @@ int orc_solve_state(const orc_params *p, const orc_state *st, double start_s, in
                     double *path_dist, int *crash_guaranteed, orc_stats *stats)
 {
     int S = orc_num_s(p, start_s), H = orc_num_t(p);
-    uint8_t *ob = (uint8_t *)malloc((size_t)H * S);
-    double *di = (double *)malloc(sizeof(double) * (size_t)H * S);
-    double *sv = (double *)malloc(sizeof(double) * S);
-    double *tv = (double *)malloc(sizeof(double) * H);
+    uint8_t *ob = (uint8_t *)orc_alloc((size_t)H * S, 0);
+    double *di = (double *)orc_alloc(sizeof(double) * (size_t)H * S, 0);
+    double *sv = (double *)orc_alloc(sizeof(double) * S, 0);
+    double *tv = (double *)orc_alloc(sizeof(double) * H, 0);
     orc_build_grid(p, st, start_s, S, H, ob, di, sv, tv, NULL);
     double c;
     if (solver == 0)
@@ -514,7 +548,7 @@ int orc_solve_state(const orc_params *p, const orc_state *st, double start_s, in
         } else if (path_dist) path_dist[t] = NAN;
     }
     if (crash_guaranteed) *crash_guaranteed = crash;
-    free(ob); free(di); free(sv); free(tv);
+    orc_release(ob); orc_release(di); orc_release(sv); orc_release(tv);
     return 0;
 }
 
@@ -534,9 +568,15 @@ static void *orc_worker(void *arg)
     int *pidx = (int *)malloc(sizeof(int) * H);
     double *pd = (double *)malloc(sizeof(double) * H);
     long long nodes = 0, edges = 0, cells = 0;
+    {   /* per-thread arena for everything one solve allocates (see orc_alloc) */
+        int Smax = orc_num_s(j->p, 0.0) + 8;
+        size_t need = (size_t)H * Smax * (1 + 8 + 4 + 1) + (size_t)Smax * 8 * 8 + (1u << 16);
+        orc_ws.base = (char *)malloc(need); orc_ws.cap = orc_ws.base ? need : 0; orc_ws.off = 0; orc_ws.active = orc_ws.base != NULL;
+    }
     for (;;) {
         int e = __sync_fetch_and_add(j->next, 1);
         if (e >= j->N) break;
+        orc_ws.off = 0;
         orc_state st;
         st.ego_x = j->ego[e * 5 + 0]; st.ego_y = j->ego[e * 5 + 1];
         st.ego_v = j->ego[e * 5 + 2]; st.ego_a = j->ego[e * 5 + 3];
@@ -554,6 +594,8 @@ static void *orc_worker(void *arg)
     __sync_fetch_and_add(&j->counters[1], edges);
     __sync_fetch_and_add(&j->counters[2], cells);
     free(sseq); free(pidx); free(pd);
+    free(orc_heap_keep.a); orc_heap_keep.a = NULL; orc_heap_keep.cap = 0;
+    free(orc_ws.base); orc_ws.base = NULL; orc_ws.cap = 0; orc_ws.active = 0;
     return NULL;
 }
 

@@ -51,6 +51,20 @@ class Stats(C.Structure):
                 ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
 
 
+class CombinedCfg(C.Structure):
+    """``stmpc_combined_cfg`` (include/stmpc.h): the flags of dqn.RLAgent.do_combined_control."""
+    _fields_ = [("tick_length", C.c_double), ("stop_x", C.c_double), ("rollout_length", C.c_int32), ("st_test_rollouts", C.c_int32),
+                ("check_rollout_crash", C.c_int32), ("limit_dqn_speed", C.c_int32), ("test_rollout_state", C.c_int32),
+                ("test_st_strictly_better", C.c_int32), ("remember_last_choice", C.c_int32)]
+
+    @classmethod
+    def from_settings(cls, S):
+        return cls(tick_length=S.TICK_LENGTH, stop_x=S.STOP_X, rollout_length=int(S.ROLLOUT_LENGTH), st_test_rollouts=int(S.ST_TEST_ROLLOUTS),
+                   check_rollout_crash=int(bool(S.CHECK_ROLLOUT_CRASH)), limit_dqn_speed=int(bool(getattr(S, "LIMIT_DQN_SPEED", False))),
+                   test_rollout_state=int(bool(S.TEST_ROLLOUT_STATE)), test_st_strictly_better=int(bool(getattr(S, "TEST_ST_STRICTLY_BETTER", False))),
+                   remember_last_choice=int(bool(getattr(S, "REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED", False))))
+
+
 class ProfileTotals(C.Structure):
     _fields_ = [("launches", C.c_int64), ("episodes", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
 
@@ -62,6 +76,7 @@ EXPORTS = (
     "stmpc_num_t", "stmpc_path_mean_abs_jerk", "stmpc_solve_batch_device", "stmpc_solve_batch", "stmpc_get_stats",
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
+    "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state",
 )
 
 QP_NMAX = 64        # STMPC_QP_NMAX
@@ -102,7 +117,11 @@ def load():
     lib.stmpc_solve_grid.argtypes = [vp, u8p, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp] + [C.c_double] * 11 + [dp]
     lib.stmpc_build_grid.argtypes = [vp, pp, dp, C.c_int, dp, dp, u8p, dp, dp, dp]
     lib.stmpc_predict_batch.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
-                                        dp, dp, dp, ip]
+                                        dp, dp, dp, ip, dp]
+    cp = C.POINTER(CombinedCfg)
+    lib.stmpc_rollout_step_device.argtypes = [vp, pp, cp, C.c_int, C.c_int, C.c_int] + [vp] * 7 + [vp]
+    lib.stmpc_combined_decide_device.argtypes = [vp, pp, cp, C.c_int, C.c_int] + [vp] * 12 + [vp]
+    lib.stmpc_combined_read_state.argtypes = [vp, C.c_int, ip, ip, ip, dp, dp, ip, dp, dp, dp, ip, dp, dp, ip]
     lib.stmpc_probe_arith.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.stmpc_profile.argtypes = [vp, C.c_int, C.POINTER(ProfileTotals)]
     lib.stmpc_finer_fit_batch.argtypes = [vp, pp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp,
@@ -295,7 +314,7 @@ class Context:
                                              _dptr(ov) if k else None, _u8ptr(ob), _dptr(di), _dptr(sv), _dptr(tv)))
         return ob.view(np.bool_), sv, tv, di
 
-    def predict_batch(self, params, mode, ego4, k_count, other_x, other_v, selected_speed, dt, min_crash_distance):
+    def predict_batch(self, params, mode, ego4, k_count, other_x, other_v, selected_speed, dt, min_crash_distance, want_acc=False):
         ego4 = np.ascontiguousarray(ego4, dtype=np.float64)
         N = ego4.shape[0]
         k_count = np.ascontiguousarray(k_count, dtype=np.int32)
@@ -307,11 +326,40 @@ class Context:
         xo = np.array(other_x, copy=True)
         vo = np.array(other_v, copy=True)
         cr = np.empty(N, dtype=np.int32)
+        ao = np.zeros_like(other_x) if want_acc else None
         self._chk(self._lib.stmpc_predict_batch(self._h, C.byref(params), int(mode), N, Kmax, _dptr(ego4), _iptr(k_count),
                                                 _dptr(other_x) if Kmax else None, _dptr(other_v) if Kmax else None,
                                                 _dptr(sel), float(dt), float(min_crash_distance), _dptr(eo),
-                                                _dptr(xo) if Kmax else None, _dptr(vo) if Kmax else None, _iptr(cr)))
+                                                _dptr(xo) if Kmax else None, _dptr(vo) if Kmax else None, _iptr(cr),
+                                                _dptr(ao) if (want_acc and Kmax) else None))
+        if want_acc:
+            return eo, xo, vo, cr, ao
         return eo, xo, vo, cr
+
+    # -- combined controller (device pointers; see include/stmpc.h) ------------------------------
+    def rollout_step_device(self, params, cfg, N, Kmax, step, d_ego5_start, d_cur_ego4, d_k, d_cur_ox, d_cur_ov, d_cur_oa, d_action, stream=0):
+        self._chk(self._lib.stmpc_rollout_step_device(self._h, C.byref(params), C.byref(cfg), int(N), int(Kmax), int(step), d_ego5_start, d_cur_ego4,
+                                                      d_k, d_cur_ox, d_cur_ov, d_cur_oa, d_action, stream))
+
+    def combined_decide_device(self, params, cfg, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, d_cur_ego4, d_cur_ox, d_cur_ov,
+                               d_first_action, d_last_choice_rl, d_takeover, d_reason, d_speed, stream=0):
+        self._chk(self._lib.stmpc_combined_decide_device(self._h, C.byref(params), C.byref(cfg), int(N), int(Kmax), d_ego5_start, d_k, d_ox_start,
+                                                         d_ov_start, d_cur_ego4, d_cur_ox, d_cur_ov, d_first_action, d_last_choice_rl,
+                                                         d_takeover, d_reason, d_speed, stream))
+
+    def combined_read_state(self, N, Kmax, rollout_length, after_decide=True):
+        """Host copies of the rollout bookkeeping (and, after the decision, of the probe / controller results)."""
+        K = max(int(Kmax), 1)
+        R1 = max(int(rollout_length), 1) + 1
+        out = {"live": np.zeros(N, np.int32), "hist_len": np.zeros(N, np.int32), "crash_pred": np.zeros(N, np.int32),
+               "sel_speed": np.zeros(N), "rollout_s": np.zeros((N, R1)), "have_test": np.zeros(N, np.int32),
+               "test_ego4": np.zeros((N, 4)), "test_ox": np.zeros((N, K)), "test_ov": np.zeros((N, K))}
+        extra = {"probe_crash": np.zeros(N, np.int32), "st_speed": np.zeros(N), "fine": np.zeros((N, QP_NMAX)), "fine_len": np.zeros(N, np.int32)} if after_decide else {}
+        self._chk(self._lib.stmpc_combined_read_state(self._h, int(N), _iptr(out["live"]), _iptr(out["hist_len"]), _iptr(out["crash_pred"]), _dptr(out["sel_speed"]),
+                                                      _dptr(out["rollout_s"]), _iptr(out["have_test"]), _dptr(out["test_ego4"]), _dptr(out["test_ox"]), _dptr(out["test_ov"]),
+                                                      _iptr(extra.get("probe_crash")), _dptr(extra.get("st_speed")), _dptr(extra.get("fine")), _iptr(extra.get("fine_len"))))
+        out.update(extra)
+        return out
 
     def probe_arith(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)

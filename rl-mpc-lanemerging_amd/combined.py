@@ -37,102 +37,96 @@ REASON_NAMES = {REASON_RL: "rl", REASON_CRASH: "crash predicted", REASON_SPEED: 
                 REASON_ROLLOUT: "st solver not happy with rollout state", REASON_ST_BETTER: "st path deemed better"}
 
 
-def _unpack(ego4, k, ox, ov, i):
+def _unpack(ego4, k, ox, ov, oa, i):
     kk = int(k[i])
     return HighwayState((float(ego4[i, 0]), float(ego4[i, 1])), float(ego4[i, 2]), float(ego4[i, 3]),
-                        [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [0.0] * kk)
+                        [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [float(x) for x in oa[i, :kk]])
+
+
+def decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_last_choice_rl=None, stream=0):
+    """One tick of ``do_combined_control`` for N states held in device tensors (torch, fp64 / int32), nothing leaves the GPU.
+
+    ``policy(step, cur_ego4, k, cur_ox, cur_ov, cur_oa) -> jerk[N]`` (fp64 device tensor) is the caller's network; it is asked once
+    per rollout step for every episode (entries of episodes whose rollout has ended are ignored, dqn.py:129-141).  Returns device
+    tensors ``takeover``, ``reason`` (REASON_*), ``speed`` (the command) and ``first_action``; the rollout bookkeeping stays in the
+    context (``ctx.combined_read_state``)."""
+    import torch
+    n, K = d_ego5.shape[0], d_ox.shape[1]
+    cur_ego4 = d_ego5[:, :4].clone().contiguous()      # (a copy: with one row the slice is already contiguous and would alias the start state)
+    cur_ox, cur_ov = d_ox.clone(), d_ov.clone()
+    cur_oa = torch.zeros_like(d_ox)
+    first_action = None
+    for step in range(1, max(int(cfg.rollout_length), 1) + 1):
+        action = policy(step, cur_ego4, d_k, cur_ox, cur_ov, cur_oa).to(torch.float64).contiguous()
+        if step == 1:
+            first_action = action.clone()
+        ctx.rollout_step_device(params, cfg, n, K, step, d_ego5.data_ptr(), cur_ego4.data_ptr(), d_k.data_ptr(), cur_ox.data_ptr(),
+                                cur_ov.data_ptr(), cur_oa.data_ptr(), action.data_ptr(), stream)
+    takeover = torch.empty(n, dtype=torch.int32, device=d_ego5.device)
+    reason = torch.empty(n, dtype=torch.int32, device=d_ego5.device)
+    speed = torch.empty(n, dtype=torch.float64, device=d_ego5.device)
+    ctx.combined_decide_device(params, cfg, n, K, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), cur_ego4.data_ptr(),
+                               cur_ox.data_ptr(), cur_ov.data_ptr(), first_action.data_ptr(),
+                               d_last_choice_rl.data_ptr() if d_last_choice_rl is not None else 0,
+                               takeover.data_ptr(), reason.data_ptr(), speed.data_ptr(), stream)
+    return {"takeover": takeover, "reason": reason, "speed": speed, "first_action": first_action}
 
 
 def decide_batch(states, get_control, ctx=None, last_choice_rl=None):
-    """Decision part of ``do_combined_control`` for a list of states.
+    """Decision part of ``do_combined_control`` for a list of states, with the reference's per-state policy callback.
 
-    Returns a dict: ``takeover[n]`` (bool), ``reason[n]`` (REASON_*), ``first_action[n]``, ``selected_speed[n]``
-    (speed of the last rollout step), ``crash_predicted[n]``, ``test_states`` (list of HighwayState, the
-    state the feasibility probe ran on), ``st_speed[n]`` (NaN unless the ST path was chosen by the
-    strictly-better comparison, dqn.py:156-197; then the speed to command).  ``get_control`` is called once per
-    live state per rollout step, in state order, exactly as the reference calls its policy.
-    ``last_choice_rl[n]``: whether the previous tick of that episode was left to the policy (dqn.py:124-126;
-    default True = empty takeover history).
+    The rollout, the feasibility probe, the controller solve and the decision run on the GPU (``decide_batch_device``); only the
+    policy callback needs the rolled-out states on the host.  Returns a dict: ``takeover[n]`` (bool), ``reason[n]`` (REASON_*),
+    ``first_action[n]``, ``selected_speed[n]`` (speed of the last rollout step), ``crash_predicted[n]``, ``test_states`` (list of
+    HighwayState, the state the feasibility probe ran on), ``st_speed[n]`` (NaN unless the ST path was chosen by the
+    strictly-better comparison, dqn.py:156-197; then the speed to command), ``speed[n]`` (the command in every case), ``rollout_s``.
+    ``get_control`` is called once per live state per rollout step, in state order, exactly as the reference calls its policy,
+    on states that carry the predictor's ``other_accelerations``.  ``last_choice_rl[n]``: whether the previous tick of that
+    episode was left to the policy (dqn.py:124-126; default True = empty takeover history).
     """
+    import torch
     ctx = ctx or _capi.default_context()
     params = _capi.Params.from_settings(Settings)
+    cfg = _capi.CombinedCfg.from_settings(Settings)
     n = len(states)
     ego5, k, ox, ov = pack_states(states)
-    ego4 = np.ascontiguousarray(ego5[:, :4])
-    first_action = np.array([get_control(s) for s in states], dtype=np.float64)
-    crash_predicted = np.zeros(n, dtype=bool)
-    selected_speed = np.zeros(n, dtype=np.float64)
-    live = np.ones(n, dtype=bool)
-    rollout_s = [[float(ego5[j, 4])] for j in range(n)]                            # dqn.py:121
-    test_ego = ego4.copy(); test_ox = ox.copy(); test_ov = ov.copy(); have_test = np.zeros(n, dtype=bool)
-    cur_ego, cur_ox, cur_ov = ego4.copy(), ox.copy(), ov.copy()
-    steps = max(Settings.ROLLOUT_LENGTH, 1)
-    for i in range(1, steps + 1):                                                 # dqn.py:129-141
-        idx = np.nonzero(live)[0]
-        if idx.size == 0:
-            break
-        if i == 1:
-            action = first_action[idx]
-        else:
-            action = np.array([get_control(_unpack(cur_ego, k, cur_ox, cur_ov, j)) for j in idx], dtype=np.float64)
-        sel = np.array([get_ego_speed_from_jerk(float(cur_ego[j, 2]), float(cur_ego[j, 3]), float(a))
-                        for j, a in zip(idx, action)], dtype=np.float64)
-        eo, xo, vo, cr = ctx.predict_batch(params, 0, cur_ego[idx], k[idx], cur_ox[idx], cur_ov[idx], sel,
-                                           Settings.TICK_LENGTH, Settings.COMBINATION_MIN_DISTANCE)
-        cur_ego[idx], cur_ox[idx], cur_ov[idx] = eo, xo, vo
-        selected_speed[idx] = sel
-        crash_predicted[idx] = cr.astype(bool)
-        if i == Settings.ST_TEST_ROLLOUTS:
-            test_ego[idx], test_ox[idx], test_ov[idx] = eo, xo, vo
-            have_test[idx] = True
-        for r, j in enumerate(idx):                                                # dqn.py:138
-            rollout_s[j].append(control.get_ego_s((float(eo[r, 0]), float(eo[r, 1]))))
-        live[idx] = ~crash_predicted[idx] & ~(eo[:, 0] > Settings.STOP_X)
-    nt = ~have_test                                                               # dqn.py:142-143
-    test_ego[nt], test_ox[nt], test_ov[nt] = cur_ego[nt], cur_ox[nt], cur_ov[nt]
+    K = ox.shape[1]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_ego5, d_k = torch.as_tensor(ego5, device=dev), torch.as_tensor(k, device=dev)
+    d_ox, d_ov = torch.as_tensor(ox, device=dev), torch.as_tensor(ov, device=dev)
+    R = max(int(Settings.ROLLOUT_LENGTH), 1)
 
-    reason = np.full(n, REASON_RL, dtype=np.int32)
-    if Settings.CHECK_ROLLOUT_CRASH:
-        reason[crash_predicted] = REASON_CRASH
-    if getattr(Settings, "LIMIT_DQN_SPEED", False):
-        m = (reason == REASON_RL) & (selected_speed > Settings.DESIRED_SPEED)
-        reason[m] = REASON_SPEED
-    test_states = [_unpack(test_ego, k, test_ox, test_ov, j) for j in range(n)]
-    if Settings.TEST_ROLLOUT_STATE:
-        idx = np.nonzero(reason == REASON_RL)[0]
-        if idx.size:
-            _, res = st.solve_states([test_states[j] for j in idx], ctx=ctx)       # one batched probe (dqn.py:152)
-            reason[idx[res["crash"].astype(bool)]] = REASON_ROLLOUT
-    st_speed = np.full(n, np.nan)
-    if getattr(Settings, "TEST_ST_STRICTLY_BETTER", False):                        # dqn.py:156-197
-        idx = np.nonzero(reason == REASON_RL)[0]
-        if idx.size:
-            last_rl = np.ones(n, dtype=bool) if last_choice_rl is None else np.asarray(last_choice_rl, dtype=bool)
-            res = ctx.st_control_batch(params, Settings.TICK_LENGTH, ego5[idx], k[idx], ox[idx], ov[idx], want_paths=True)
-            for r, j in enumerate(idx):
-                m = int(res["fine_len"][r])
-                if m < 0:
-                    raise ValueError("finer_fit: more than %d fine samples are not supported" % _capi.QP_NMAX)
-                s_seq = res["fine"][r, :m]                                          # trimmed, QP-resampled when TICK < T_DISCRETIZATION
-                if m <= 1:                                                         # dqn.py:167-169
-                    continue
-                hist = rollout_s[j]
-                ml = min(m, len(hist))
-                v0, a0 = float(ego5[j, 2]), float(ego5[j, 3])
-                st_jerk = st.get_path_mean_abs_jerk(s_seq[:ml], v0, a0, Settings.TICK_LENGTH)
-                rl_jerk = st.get_path_mean_abs_jerk(hist[:ml], v0, a0, Settings.TICK_LENGTH)
-                st_distance = s_seq[ml - 1] - s_seq[0]
-                rl_distance = hist[ml - 1] - hist[0]
-                if last_rl[j] or not Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED:
-                    choose_st = (st_jerk < rl_jerk and st_distance > rl_distance) or rl_distance == 0
-                else:
-                    choose_st = not (rl_jerk < st_jerk and rl_distance > st_distance)
-                if choose_st:
-                    reason[j] = REASON_ST_BETTER
-                    st_speed[j] = (s_seq[1] - s_seq[0]) / Settings.TICK_LENGTH     # dqn.py:180-181,192-193
-    return {"takeover": reason != REASON_RL, "reason": reason, "first_action": first_action,
-            "selected_speed": selected_speed, "crash_predicted": crash_predicted, "test_states": test_states,
-            "st_speed": st_speed, "rollout_s": rollout_s}
+    def policy(step, cur_ego4, d_k_, cur_ox, cur_ov, cur_oa):
+        if step == 1:
+            act = np.array([get_control(s) for s in states], dtype=np.float64)
+        else:
+            live = ctx.combined_read_state(n, K, R, after_decide=False)["live"].astype(bool)
+            e4, xo, vo, ao = cur_ego4.cpu().numpy(), cur_ox.cpu().numpy(), cur_ov.cpu().numpy(), cur_oa.cpu().numpy()
+            act = np.zeros(n)
+            for j in np.nonzero(live)[0]:
+                act[j] = get_control(_unpack(e4, k, xo, vo, ao, j))
+        return torch.as_tensor(act, device=dev)
+
+    d_last = None
+    if last_choice_rl is not None:
+        d_last = torch.as_tensor(np.asarray(last_choice_rl, dtype=bool).astype(np.int32), device=dev)
+    d = decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_last)
+    torch.cuda.synchronize()
+    st_ = ctx.combined_read_state(n, K, R, after_decide=True)
+    reason = d["reason"].cpu().numpy()
+    speed = d["speed"].cpu().numpy()
+    hist = [list(st_["rollout_s"][j, :st_["hist_len"][j]]) for j in range(n)]
+    # the probe state: the state after ST_TEST_ROLLOUTS steps, else the last rolled-out state (dqn.py:137-143)
+    test_states = []
+    for j in range(n):
+        if st_["have_test"][j]:
+            test_states.append(_unpack(st_["test_ego4"], k, st_["test_ox"], st_["test_ov"], np.zeros_like(ox), j))
+        else:
+            test_states.append(None)
+    st_speed = np.where(reason == REASON_ST_BETTER, speed, np.nan)
+    return {"takeover": reason != REASON_RL, "reason": reason, "first_action": d["first_action"].cpu().numpy(),
+            "selected_speed": st_["sel_speed"], "crash_predicted": st_["crash_pred"].astype(bool), "test_states": test_states,
+            "st_speed": st_speed, "speed": speed, "rollout_s": hist}
 
 
 class CombinedController:
@@ -146,17 +140,14 @@ class CombinedController:
         last_choice_rl = not (len(self.takeover_history) > 0 and self.takeover_history[-1])     # dqn.py:124-126
         d = decide_batch([state], self.get_control, last_choice_rl=[last_choice_rl])
         take = bool(d["takeover"][0])
+        reason = int(d["reason"][0])
         self.takeover_history.append(take)
-        if int(d["reason"][0]) == REASON_ST_BETTER:
+        speed = float(d["speed"][0])
+        if reason == REASON_ST_BETTER:
             if last_choice_rl or not Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED:
                 print("ST Path deemed better")
-            speed = float(d["st_speed"][0])
-            control.set_ego_speed(speed)
-            return speed
-        if take:
+        elif take:
             print({REASON_CRASH: "Crash predicted", REASON_SPEED: "DDPG going too fast",
-                   REASON_ROLLOUT: "ST solver not happy with rollout state"}[int(d["reason"][0])])
-            return st.do_st_control(state)
-        new_speed = get_ego_speed_from_jerk(state.ego_speed, state.ego_acceleration, float(d["first_action"][0]))
-        control.set_ego_speed(new_speed)                                          # control.set_ego_jerk, control.py:174-178
-        return new_speed
+                   REASON_ROLLOUT: "ST solver not happy with rollout state"}[reason])
+        control.set_ego_speed(speed)           # st.do_st_control / control.set_ego_speed / control.set_ego_jerk all end here (st.py:782, control.py:174-178)
+        return speed

@@ -3,6 +3,7 @@
 // No CPU fallback: every compute entry needs a HIP device.
 #include "stmpc_kernels.hpp"
 #include "stmpc_ff_kernels.hpp"
+#include "stmpc_cc_kernels.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -70,6 +71,10 @@ struct stmpc_ctx {
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
     DevBuf ckpt, resume_t, phase_prof;
+    // combined controller (stmpc_rollout_step_device / stmpc_combined_decide_device): rollout bookkeeping and probe / controller outputs
+    DevBuf cc_live, cc_hist_len, cc_crash_pred, cc_have_test, cc_sel, cc_rollout_s, cc_test_ego, cc_test_ox, cc_test_ov, cc_probe_ego, cc_probe_ox, cc_probe_ov,
+        cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err;
+    int cc_N = 0, cc_K = 0, cc_R = 0;
     DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
@@ -220,7 +225,9 @@ void stmpc_destroy(stmpc_ctx *c) {
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
-                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
+                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
+                     &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
+                     &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -750,7 +757,7 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
 
 int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, int Kmax, const double *ego4,
                         const int32_t *k, const double *ox, const double *ov, const double *sel, double dt,
-                        double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed) {
+                        double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed, double *oa_out) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
     if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || (mode != 0 && mode != 1)) return fail(STMPC_EINVAL, "bad N/Kmax/mode");
     if (N == 0) return STMPC_OK;
@@ -771,6 +778,8 @@ int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, in
     if ((rc = c->s_misc2.ensure((size_t)N * Kalloc * 8))) return rc;
     if ((rc = c->s_misc3.ensure((size_t)N * Kalloc * 8))) return rc;
     if ((rc = c->s_crash.ensure((size_t)N * 4))) return rc;
+    if (oa_out && (rc = c->s_pd.ensure((size_t)N * Kalloc * 8))) return rc;
+    if (oa_out) HIPCHK(hipMemset(c->s_pd.p, 0, (size_t)N * Kalloc * 8));
     HIPCHK(hipMemcpy(c->s_ego.p, ego4, (size_t)N * 4 * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_k.p, k, (size_t)N * 4, hipMemcpyHostToDevice));
     if (Kmax > 0) {
@@ -782,7 +791,8 @@ int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, in
 #define STMPC_LAUNCH_STEP(KM)                                                                                         \
     hipLaunchKernelGGL(k_predict_step<KM>, dim3(blocks), dim3(64), 0, nullptr, dp, mode, N, Kalloc, c->s_ego.as<double>(), \
                        c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), c->s_misc0.as<double>(), dt, mcd,   \
-                       c->s_misc1.as<double>(), c->s_misc2.as<double>(), c->s_misc3.as<double>(), c->s_crash.as<int>())
+                       c->s_misc1.as<double>(), c->s_misc2.as<double>(), c->s_misc3.as<double>(), c->s_crash.as<int>(), \
+                       oa_out ? c->s_pd.as<double>() : (double *)nullptr)
     if (Kalloc <= 8) STMPC_LAUNCH_STEP(8);
     else if (Kalloc <= 16) STMPC_LAUNCH_STEP(16);
     else STMPC_LAUNCH_STEP(32);
@@ -795,6 +805,7 @@ int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, in
         HIPCHK(hipMemcpy(ov_out, c->s_misc3.p, (size_t)N * Kmax * 8, hipMemcpyDeviceToHost));
     }
     HIPCHK(hipMemcpy(crashed, c->s_crash.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (oa_out && Kmax > 0) HIPCHK(hipMemcpy(oa_out, c->s_pd.p, (size_t)N * Kmax * 8, hipMemcpyDeviceToHost));
     return STMPC_OK;
 }
 
@@ -971,3 +982,143 @@ int stmpc_st_control_batch(stmpc_ctx *c, const stmpc_params *p, double tick, int
 
 }  // extern "C"
 
+namespace {
+int make_ccfg(const stmpc_params *p, const stmpc_combined_cfg *g, CCfg *c) {
+    if (!p || !g) return fail(STMPC_EINVAL, "params / combined cfg is NULL");
+    if (!(g->tick_length > 0)) return fail(STMPC_EINVAL, "tick_length must be positive");
+    memset(c, 0, sizeof *c);
+    c->tick = g->tick_length; c->comb_min_dist = p->comb_min_dist; c->stop_x = g->stop_x;
+    c->a_max = p->a_max; c->a_min = p->a_min; c->v_max = p->v_max; c->desired_speed = p->v_des;
+    c->rollout_length = g->rollout_length > 1 ? g->rollout_length : 1;            // max(ROLLOUT_LENGTH, 1), dqn.py:129
+    c->st_test_rollouts = g->st_test_rollouts; c->check_rollout_crash = g->check_rollout_crash; c->limit_speed = g->limit_dqn_speed;
+    c->test_rollout_state = g->test_rollout_state; c->strictly_better = g->test_st_strictly_better; c->remember_last = g->remember_last_choice;
+    if (c->rollout_length > STMPC_ROLLOUT_LIMIT) return fail(STMPC_EINVAL, "rollout_length above STMPC_ROLLOUT_LIMIT");
+    return STMPC_OK;
+}
+int cc_ensure(stmpc_ctx *c, int N, int K, int R) {
+    int rc;
+    if ((rc = c->cc_live.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_hist_len.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_crash_pred.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_have_test.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_sel.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->cc_rollout_s.ensure((size_t)N * (R + 1) * 8))) return rc;
+    if ((rc = c->cc_test_ego.ensure((size_t)N * 4 * 8))) return rc;
+    if ((rc = c->cc_test_ox.ensure((size_t)N * K * 8))) return rc;
+    if ((rc = c->cc_test_ov.ensure((size_t)N * K * 8))) return rc;
+    c->cc_N = N; c->cc_K = K; c->cc_R = R;
+    return STMPC_OK;
+}
+CCState cc_state(stmpc_ctx *c) {
+    return CCState{c->cc_live.as<int>(), c->cc_hist_len.as<int>(), c->cc_crash_pred.as<int>(), c->cc_have_test.as<int>(), c->cc_sel.as<double>(),
+                   c->cc_rollout_s.as<double>(), c->cc_test_ego.as<double>(), c->cc_test_ox.as<double>(), c->cc_test_ov.as<double>()};
+}
+}  // namespace
+
+extern "C" {
+
+int stmpc_rollout_step_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_combined_cfg *g, int N, int Kmax, int step,
+                              const double *d_ego5_start, double *d_cur_ego4, const int32_t *d_k, double *d_cur_ox, double *d_cur_ov,
+                              double *d_cur_oa, const double *d_action, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || step < 1) return fail(STMPC_EINVAL, "N, Kmax or step out of range");
+    if (N == 0) return STMPC_OK;
+    if (!d_ego5_start || !d_cur_ego4 || !d_k || !d_action) return fail(STMPC_EINVAL, "NULL device pointer");
+    if (Kmax > 0 && (!d_cur_ox || !d_cur_ov)) return fail(STMPC_EINVAL, "NULL device pointer (vehicles)");
+    HIPCHK(hipSetDevice(c->device));
+    DevP dp; CCfg cc;
+    int rc = make_devp(p, &dp);
+    if (rc) return rc;
+    if ((rc = make_ccfg(p, g, &cc))) return rc;
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+    if (step == 1) { if ((rc = cc_ensure(c, N, Kalloc, cc.rollout_length))) return rc; }
+    else if (c->cc_N != N || c->cc_K != Kalloc || c->cc_R != cc.rollout_length) return fail(STMPC_EINVAL, "rollout step > 1 does not continue the rollout begun with step 1");
+    CCState st = cc_state(c);
+    const int blocks = (N + 63) / 64;
+#define STMPC_RS(KM) hipLaunchKernelGGL(k_rollout_step<KM>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dp, cc, N, Kalloc, step, d_ego5_start, d_cur_ego4, d_k, d_cur_ox, d_cur_ov, d_cur_oa, d_action, st)
+    if (Kalloc <= 8) STMPC_RS(8); else if (Kalloc <= 16) STMPC_RS(16); else STMPC_RS(32);
+#undef STMPC_RS
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_combined_cfg *g, int N, int Kmax,
+                                 const double *d_ego5_start, const int32_t *d_k, const double *d_ox_start, const double *d_ov_start,
+                                 const double *d_cur_ego4, const double *d_cur_ox, const double *d_cur_ov, const double *d_first_action,
+                                 const int32_t *d_last_choice_rl, int32_t *d_takeover, int32_t *d_reason, double *d_speed, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N == 0) return STMPC_OK;
+    if (!d_ego5_start || !d_k || !d_cur_ego4 || !d_first_action || !d_takeover || !d_reason || !d_speed) return fail(STMPC_EINVAL, "NULL device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    CCfg cc;
+    int rc = make_ccfg(p, g, &cc);
+    if (rc) return rc;
+    const int Kalloc = Kmax > 0 ? Kmax : 1;
+    if (c->cc_N != N || c->cc_K != Kalloc || c->cc_R != cc.rollout_length) return fail(STMPC_EINVAL, "no rollout of this shape in the context (call stmpc_rollout_step_device first)");
+    const int H = stmpc_num_t(p);
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "number of time layers must be in [2, 64]");
+    hipStream_t st_ = (hipStream_t)stream;
+    if ((rc = c->cc_probe_ego.ensure((size_t)N * 5 * 8))) return rc;
+    if ((rc = c->cc_probe_ox.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->cc_probe_ov.ensure((size_t)N * Kalloc * 8))) return rc;
+    if ((rc = c->cc_path.ensure((size_t)N * H * 4))) return rc;
+    if ((rc = c->cc_bt.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_cost.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->cc_pcrash.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_speed.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->cc_fine.ensure((size_t)N * STMPC_QP_NMAX * 8))) return rc;
+    if ((rc = c->cc_fine_len.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->cc_err.ensure(4))) return rc;
+    CCState st = cc_state(c);
+    const int blocks = (N + 63) / 64;
+    HIPCHK(hipMemsetAsync(c->cc_err.p, 0, 4, st_));
+    HIPCHK(hipMemsetAsync(c->cc_pcrash.p, 0, (size_t)N * 4, st_));
+    // 1. feasibility probe of the rolled-out state (st.test_guaranteed_crash_from_state, dqn.py:152): one batched solve
+    if (cc.test_rollout_state) {
+        hipLaunchKernelGGL(k_cc_probe_state, dim3(blocks), dim3(64), 0, st_, N, Kalloc, d_cur_ego4, d_cur_ox, d_cur_ov, st, c->cc_probe_ego.as<double>(),
+                           c->cc_probe_ox.as<double>(), c->cc_probe_ov.as<double>());
+        if ((rc = stmpc_solve_batch_device(c, p, N, Kmax, c->cc_probe_ego.as<double>(), d_k, c->cc_probe_ox.as<double>(), c->cc_probe_ov.as<double>(),
+                                           c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(), c->cc_cost.as<double>(), nullptr, c->cc_pcrash.as<int32_t>(), stream))) return rc;
+    }
+    // 2. the controller on the start state (st.do_st_control; also the path of the strictly-better comparison, dqn.py:157-164)
+    HIPCHK(hipMemsetAsync(c->cc_fine.p, 0, (size_t)N * STMPC_QP_NMAX * 8, st_));
+    if ((rc = stmpc_st_control_batch_device(c, p, g->tick_length, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(),
+                                            c->cc_cost.as<double>(), c->cc_speed.as<double>(), c->cc_fine.as<double>(), c->cc_fine_len.as<int32_t>(), stream))) return rc;
+    // 3. the decision
+    hipLaunchKernelGGL(k_cc_decide, dim3(blocks), dim3(64), 0, st_, cc, N, d_ego5_start, d_first_action, d_last_choice_rl, st, (const int *)c->cc_pcrash.as<int>(),
+                       (const double *)c->cc_speed.as<double>(), (const double *)c->cc_fine.as<double>(), (const int *)c->cc_fine_len.as<int>(), STMPC_QP_NMAX,
+                       d_takeover, d_reason, d_speed, c->cc_err.as<unsigned>());
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_combined_read_state(stmpc_ctx *c, int N, int32_t *live, int32_t *hist_len, int32_t *crash_pred, double *sel_speed, double *rollout_s,
+                              int32_t *have_test, double *test_ego4, double *test_ox, double *test_ov, int32_t *probe_crash, double *st_speed,
+                              double *fine, int32_t *fine_len) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N != c->cc_N) return fail(STMPC_EINVAL, "no rollout of this size in the context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t K = c->cc_K, R1 = c->cc_R + 1;
+    if (live) HIPCHK(hipMemcpy(live, c->cc_live.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (hist_len) HIPCHK(hipMemcpy(hist_len, c->cc_hist_len.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (crash_pred) HIPCHK(hipMemcpy(crash_pred, c->cc_crash_pred.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (sel_speed) HIPCHK(hipMemcpy(sel_speed, c->cc_sel.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (rollout_s) HIPCHK(hipMemcpy(rollout_s, c->cc_rollout_s.p, (size_t)N * R1 * 8, hipMemcpyDeviceToHost));
+    if (have_test) HIPCHK(hipMemcpy(have_test, c->cc_have_test.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (test_ego4) HIPCHK(hipMemcpy(test_ego4, c->cc_test_ego.p, (size_t)N * 4 * 8, hipMemcpyDeviceToHost));
+    if (test_ox) HIPCHK(hipMemcpy(test_ox, c->cc_test_ox.p, (size_t)N * K * 8, hipMemcpyDeviceToHost));
+    if (test_ov) HIPCHK(hipMemcpy(test_ov, c->cc_test_ov.p, (size_t)N * K * 8, hipMemcpyDeviceToHost));
+    if (probe_crash && c->cc_pcrash.p) HIPCHK(hipMemcpy(probe_crash, c->cc_pcrash.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (st_speed && c->cc_speed.p) HIPCHK(hipMemcpy(st_speed, c->cc_speed.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (fine && c->cc_fine.p) HIPCHK(hipMemcpy(fine, c->cc_fine.p, (size_t)N * STMPC_QP_NMAX * 8, hipMemcpyDeviceToHost));
+    if (fine_len && c->cc_fine_len.p) HIPCHK(hipMemcpy(fine_len, c->cc_fine_len.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (c->cc_err.p) {
+        unsigned e = 0;
+        HIPCHK(hipMemcpy(&e, c->cc_err.p, 4, hipMemcpyDeviceToHost));
+        if (e) return fail(STMPC_EINVAL, "finer_fit: a fine grid longer than STMPC_QP_NMAX samples is not supported");
+    }
+    return STMPC_OK;
+}
+
+}  // extern "C"

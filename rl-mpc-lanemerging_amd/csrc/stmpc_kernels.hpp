@@ -41,13 +41,17 @@ typedef unsigned short u16;
 // the totals to SolveArgs::phase_prof[pass][phase] when the pass ends.  Compiled out of the product build.
 #ifdef STMPC_PHASE_PROF
 #define STMPC_NPH 16
-#define STMPC_PH_DECL unsigned long long ph_acc_[STMPC_NPH] = {0}; unsigned long long ph_t_ = __builtin_readcyclecounter();
+#define STMPC_PH_DECL unsigned long long ph_acc_[STMPC_NPH] = {0}; unsigned long long ph_t_ = __builtin_readcyclecounter(); unsigned long long ph_cand_ = 0, ph_slots_ = 0;
 #define STMPC_PH(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc_[k] += n_ - ph_t_; ph_t_ = n_; } } while (0)
-#define STMPC_PH_FLUSH(mode) do { if (threadIdx.x == 0 && a.phase_prof) for (int k_ = 0; k_ < STMPC_NPH; ++k_) atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + k_], ph_acc_[k_]); } while (0)
+#define STMPC_PH_FLUSH(mode) do { if (threadIdx.x == 0 && a.phase_prof) for (int k_ = 0; k_ < 14; ++k_) atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + k_], ph_acc_[k_]); \
+                                   if ((threadIdx.x & 63) == 0 && a.phase_prof) { atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 14], ph_cand_); atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 15], ph_slots_); } } while (0)
+// slots 14 / 15 of a pass: candidate evaluations that were offered to a cell / lane-slots the waves executed (64 per slot)
+#define STMPC_PH_CAND(okflag) do { ph_cand_ += (unsigned long long)__popcll(__ballot(okflag)); ph_slots_ += 64ull; } while (0)
 #else
 #define STMPC_PH_DECL
 #define STMPC_PH(k) do { } while (0)
 #define STMPC_PH_FLUSH(mode) do { } while (0)
+#define STMPC_PH_CAND(okflag) do { } while (0)
 #endif
 
 namespace stmpc {
@@ -127,7 +131,7 @@ struct DState {
 // prediction.py:46-105 (in place). Returns the crash flag.
 template <int KMAX>
 __device__ __forceinline__ bool dev_predict_with_ego(const DevP &p, DState<KMAX> &s, double sel,
-                                                     double dt, double min_crash_distance) {
+                                                     double dt, double min_crash_distance, double *acc_out = nullptr) {
     const double mp2x = 1.5, mp2y = -1.5;
     double cx = s.ex, cy = s.ey, px, py;
     if (cx < mp2x) {
@@ -159,10 +163,12 @@ __device__ __forceinline__ bool dev_predict_with_ego(const DevP &p, DState<KMAX>
             double sd = last_speed - ov;
             double xd = last_x - ox;
             double nv;
+            double acc = 0.0;                                     // new_other_acceleration, prediction.py:86,89
             if (sd < 0 && xd < p.follow_gap) {
-                double acc = dmax_py(sd, p.max_pred_decel);
+                acc = dmax_py(sd, p.max_pred_decel);
                 nv = ov + acc * dt;
             } else nv = ov;
+            if (acc_out) acc_out[i] = acc;
             double nx = ox + nv * dt;
             last_x = nx; last_speed = nv;
             s.xs[i] = nx; s.vs[i] = nv;
@@ -180,7 +186,7 @@ __device__ __forceinline__ bool dev_predict_with_ego(const DevP &p, DState<KMAX>
 // prediction.py:22-44 (in place)
 template <int KMAX>
 __device__ __forceinline__ bool dev_predict_without_ego(const DevP &p, DState<KMAX> &s, double dt,
-                                                        double min_crash_distance) {
+                                                        double min_crash_distance, double *acc_out = nullptr) {
     double ego_s = dev_ego_s(s.ex, s.ey);
     double ego_x = s.ex;
     double sel = 0.0;
@@ -201,7 +207,7 @@ __device__ __forceinline__ bool dev_predict_without_ego(const DevP &p, DState<KM
         if (found) { s.ex = last_x - p.car_length - 5; s.ev = last_speed; s.ea = 0.0; }
         sel = last_speed;
     }
-    return dev_predict_with_ego<KMAX>(p, s, sel, dt, min_crash_distance);
+    return dev_predict_with_ego<KMAX>(p, s, sel, dt, min_crash_distance, acc_out);
 }
 
 // Per-(episode, layer) list of obstructing vehicles.
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
     double start_s = ego[e * 5 + 4];
     int k = k_count[e];
     k = k < 0 ? 0 : (k > KMAX ? KMAX : k);
+    k = k > Kmax ? Kmax : k;                 // the table rows hold Kmax entries (device-pointer callers are not validated on the host)
     s.k = k;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
@@ -284,13 +291,15 @@ __global__ void __launch_bounds__(64) k_predict_step(DevP p, int mode, int N, in
                                                      const double *__restrict__ ego4, const int *__restrict__ k_count,
                                                      const double *__restrict__ other_x, const double *__restrict__ other_v,
                                                      const double *__restrict__ sel, double dt, double mcd,
-                                                     double *ego4_out, double *ox_out, double *ov_out, int *crashed) {
+                                                     double *ego4_out, double *ox_out, double *ov_out, int *crashed,
+                                                     double *oa_out /* [N][Kmax] or null: new_other_accelerations */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     DState<KMAX> s;
     s.ex = ego4[e * 4 + 0]; s.ey = ego4[e * 4 + 1]; s.ev = ego4[e * 4 + 2]; s.ea = ego4[e * 4 + 3];
     int k = k_count[e];
     k = k < 0 ? 0 : (k > KMAX ? KMAX : k);
+    k = k > Kmax ? Kmax : k;                 // never beyond the row stride of the caller's arrays
     s.k = k;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
@@ -298,12 +307,15 @@ __global__ void __launch_bounds__(64) k_predict_step(DevP p, int mode, int N, in
         s.xs[i] = in ? other_x[(size_t)e * Kmax + i] : 0.0;
         s.vs[i] = in ? other_v[(size_t)e * Kmax + i] : 0.0;
     }
-    bool cr = (mode == 0) ? dev_predict_with_ego<KMAX>(p, s, sel[e], dt, mcd)
-                          : dev_predict_without_ego<KMAX>(p, s, dt, mcd);
+    double acc[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) acc[i] = 0.0;
+    bool cr = (mode == 0) ? dev_predict_with_ego<KMAX>(p, s, sel[e], dt, mcd, acc)
+                          : dev_predict_without_ego<KMAX>(p, s, dt, mcd, acc);
     ego4_out[e * 4 + 0] = s.ex; ego4_out[e * 4 + 1] = s.ey; ego4_out[e * 4 + 2] = s.ev; ego4_out[e * 4 + 3] = s.ea;
 #pragma unroll
     for (int i = 0; i < KMAX; ++i)
-        if (i < k && i < Kmax) { ox_out[(size_t)e * Kmax + i] = s.xs[i]; ov_out[(size_t)e * Kmax + i] = s.vs[i]; }
+        if (i < k && i < Kmax) { ox_out[(size_t)e * Kmax + i] = s.xs[i]; ov_out[(size_t)e * Kmax + i] = s.vs[i]; if (oa_out) oa_out[(size_t)e * Kmax + i] = acc[i]; }
     crashed[e] = cr ? 1 : 0;
 }
 
@@ -941,6 +953,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             const double tot = C + ec;                       // st_cy.pyx:388
                             const bool ok = (n < hi) & (pn[u] >= 0.0);       // st_cy.pyx:379,383
                             tb[ub + u] = ok ? (u64)__double_as_longlong(tot) : ~0ull;
+                            STMPC_PH_CAND(ok);
                             if constexpr (MODE == PASS_BOUND) { if (tb[ub + u] < my_min_tot) my_min_tot = tb[ub + u]; }
                         }
 #pragma unroll

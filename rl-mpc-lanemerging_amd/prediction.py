@@ -37,14 +37,12 @@ class HighwayState:
         ox = np.asarray(self.other_xs, dtype=np.float64).reshape(1, k)
         ov = np.asarray(self.other_speeds, dtype=np.float64).reshape(1, k)
         sel = np.array([selected_speed], dtype=np.float64)
-        eo, xo, vo, cr = _capi.default_context().predict_batch(params, mode, ego4, np.array([k], np.int32), ox, ov, sel,
-                                                               delta_t, min_crash_distance)
-        new_vs = [float(v) for v in vo[0]]
-        # new_other_acceleration of prediction.py:86-89 is (new_speed - old_speed)/dt up to rounding; the
-        # reference never reads it back, it is carried for shape compatibility only.
-        new_acc = [(nv - float(v)) / delta_t for nv, v in zip(new_vs, self.other_speeds)]
+        eo, xo, vo, cr, ao = _capi.default_context().predict_batch(params, mode, ego4, np.array([k], np.int32), ox, ov, sel,
+                                                                   delta_t, min_crash_distance, want_acc=True)
+        # new_other_accelerations (prediction.py:86-89,97): the deceleration applied to a following vehicle, else 0 -- the
+        # RL policy's state vector reads them (dqn.get_state_vector_from_base_state, dqn.py:400), so they come from the predictor itself
         st = HighwayState((float(eo[0, 0]), float(eo[0, 1])), float(eo[0, 2]), float(eo[0, 3]),
-                          [float(x) for x in xo[0]], new_vs, new_acc)
+                          [float(x) for x in xo[0]], [float(v) for v in vo[0]], [float(a) for a in ao[0]])
         return st, bool(cr[0])
 
     def predict_step_without_ego(self, delta_t, min_crash_distance=5):
@@ -60,25 +58,13 @@ class HighwayState:
         return cls(0, 0, 0, [], [], [])
 
     def get_closest_cars(self):
-        """prediction.py:162-182 (pure bookkeeping)."""
-        ego_x, ego_y = self.ego_position
-        index_behind = -1
-        index_front = -1
-        last_index = -1
-        for other_index, x in enumerate(self.other_xs):
-            if x < ego_x:
-                index_behind = other_index
-                break
-            last_index = other_index
-        if last_index != -1:
-            index_front = last_index
-        car_front = None
-        car_behind = None
-        if index_front != -1:
-            car_front = (self.other_xs[index_front], self.other_speeds[index_front], self.other_accelerations[index_front])
-        if index_behind != -1:
-            car_behind = (self.other_xs[index_behind], self.other_speeds[index_behind], self.other_accelerations[index_behind])
-        return car_front, car_behind
+        """Nearest vehicle ahead of and behind the ego as ``(x, speed, acceleration)`` or ``None`` (same result as
+        the reference's ``prediction.py:162-182``; vehicles are ordered front to back)."""
+        ego_x = self.ego_position[0]
+        triple = lambda i: (self.other_xs[i], self.other_speeds[i], self.other_accelerations[i])
+        behind = next((i for i, x in enumerate(self.other_xs) if x < ego_x), None)
+        n_front = behind if behind is not None else len(self.other_xs)
+        return (triple(n_front - 1) if n_front > 0 else None), (triple(behind) if behind is not None else None)
 
 
 def pack_states(states, kmax=None):

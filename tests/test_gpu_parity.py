@@ -10,7 +10,7 @@ from conftest import load_golden, settings_from_golden
 
 pytestmark = pytest.mark.gpu
 
-STATE_FILES = ["golden_default.npz", "golden_uncertainty.npz", "golden_h40a21.npz"]
+STATE_FILES = ["golden_default.npz", "golden_uncertainty.npz", "golden_h40a21.npz", "golden_h40a21_unc.npz"]
 
 
 def _check(res, ref, H):
@@ -220,6 +220,63 @@ def test_predictor_steps_match_reference(gpu_ctx, restore_settings):
             assert np.array_equal(eo, g["without_ego"][m])
             assert np.array_equal(xo[mask], g["without_x"][m][mask]) and np.array_equal(vo[mask], g["without_v"][m][mask])
             assert np.array_equal(cr, g["without_crash"][m])
+
+
+def test_predictor_thresholds_match_reference(gpu_ctx, restore_settings):
+    """Predicted ego within 1e-9 of the reaction (8) / crash (11) thresholds: the device's arclength map (x*x for the
+    squares where CPython calls pow) must take the reference's side of every comparison."""
+    g = load_golden("golden_thresholds.npz")
+    d = load_golden("golden_default.npz")
+    p, op = settings_from_golden(d)
+    for dt in (0.2, 0.3):
+        m = g["dt"] == dt
+        eo, xo, vo, cr = gpu_ctx.predict_batch(p, 0, g["ego"][m, :4], g["k_count"][m], g["other_x"][m], g["other_v"][m], g["sel"][m], dt, 5.0)
+        kk = g["k_count"][m]
+        mask = np.arange(g["other_x"].shape[1])[None, :] < kk[:, None]
+        assert np.array_equal(eo, g["with_ego"][m])
+        assert np.array_equal(xo[mask], g["with_x"][m][mask]) and np.array_equal(vo[mask], g["with_v"][m][mask])
+        assert np.array_equal(cr, g["with_crash"][m])
+
+
+def test_config4_shard_properties(gpu_ctx, restore_settings):
+    """BASELINE configs[3] per-rank shard: 8192 episodes (65536 over 8 GPUs) at H=40, S=7201 on one GPU --
+    idempotence, sub-batch consistency, structure of every path, and 128 episodes bit-for-bit against the heap restatement."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    H = _capi.num_t(p)
+    n = 8192
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=1003)
+    r1 = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
+    r2 = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
+    for key in ("path_idx", "best_t", "cost", "crash"):
+        assert np.array_equal(r1[key], r2[key])
+    r4 = st.solve_arrays(ego[4096:4096 + 257], kc[4096:4096 + 257], ox[4096:4096 + 257], ov[4096:4096 + 257], p, gpu_ctx)
+    assert np.array_equal(r4["path_idx"], r1["path_idx"][4096:4096 + 257]) and np.array_equal(r4["cost"], r1["cost"][4096:4096 + 257])
+    path, bt = r1["path_idx"], r1["best_t"]
+    valid = np.arange(H)[None, :] <= bt[:, None]
+    assert (path[:, 0] == 0).all() and ((path >= 0) == valid).all()
+    dd = np.diff(path, axis=1)
+    assert (dd[valid[:, 1:]] >= 0).all() and (dd[valid[:, 1:]] <= p.v_max * p.dt / p.ds + 1).all()
+    assert ((bt < H - 1) <= (r1["crash"] == 1)).all()
+    op = orc.OrcParams.from_dict(p.as_dict())
+    sel = np.arange(0, n, 64)
+    ref = orc.solve_batch(op, ego[sel], kc[sel], ox[sel], ov[sel], solver="heap", nthreads=8)
+    assert np.array_equal(ref["path_idx"], path[sel]) and np.array_equal(ref["cost"], r1["cost"][sel]) and np.array_equal(ref["best_t"], bt[sel])
+
+
+def test_bench_forced_rccl_single_rank():
+    """bench.py's collective path on one GPU: a 1-rank RCCL group, all_gather of (action, cost) checked against the solver's outputs."""
+    import json, subprocess, sys
+    env = dict(os.environ, STMPC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"),
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--episodes", "512"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "all_gather" in line["config"]["collective"] and line["value"] > 0
 
 
 def test_edge_cases(gpu_ctx, restore_settings):
