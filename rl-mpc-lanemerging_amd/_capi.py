@@ -93,6 +93,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and must be the first to load it, otherwise the
+    # system copy this library links against initialises the device and torch then reports "No HIP GPUs are available"
+    # (and device pointers could not be shared).  With torch imported first the loader resolves this library's
+    # libamdhip64 dependency to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "

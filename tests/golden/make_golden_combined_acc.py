@@ -54,6 +54,11 @@ def main():
     dqn.print = lambda *a, **kw: msgs.append(str(a[0]))
     st.do_st_control = lambda state: calls.setdefault("st", True) and "ST"
     control.set_ego_jerk = lambda jerk: calls.setdefault("rl", jerk) and "RL"
+    speeds = []
+    orig_speed_from_jerk = control.get_ego_speed_from_jerk
+    def rec_speed(v, a, j):
+        r = orig_speed_from_jerk(v, a, j); speeds.append(float(r)); return r
+    control.get_ego_speed_from_jerk = rec_speed            # dqn.py:135 looks it up as control.<name> at call time
     ego, k, ox, ov = synth.generate_states(400, k=7, kmax=8, seed=77, vary_k=True, dt=0.2, blocked_quota=0.02)
     ego[:, 0] = np.random.default_rng(6).uniform(-60.0, 45.0, ego.shape[0])      # merged or about to: followers react to the ego
     ego[:, 1] = synth.road_y(ego[:, 0])
@@ -61,25 +66,28 @@ def main():
     out = {}
     for name, fn in (("acc", acc_policy), ("noacc", stub_policy)):
         takeover = np.zeros(len(k), dtype=np.int32); reason = np.zeros(len(k), dtype=np.int32); seen = np.zeros(len(k), dtype=np.int32)
+        last_speed = np.zeros(len(k)); n_steps = np.zeros(len(k), dtype=np.int32)
         for i in range(len(k)):
             kk = int(k[i])
             state = prediction.HighwayState((float(ego[i, 0]), float(ego[i, 1])), float(ego[i, 2]), float(ego[i, 3]),
                                             [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [0.0] * kk)
             ego[i, 4] = control.get_ego_s(state.ego_position)
             agent = Agent(); agent.fn = fn; agent.seen_acc = False
-            calls.clear(); msgs.clear()
+            calls.clear(); msgs.clear(); speeds.clear()
             agent.do_combined_control(state)
             reason[i] = codes[msgs[0]] if msgs else 0
             takeover[i] = int(agent.takeover_history[0]); seen[i] = int(agent.seen_acc)
-        out[name] = (takeover, reason, seen)
+            last_speed[i] = speeds[-1]; n_steps[i] = len(speeds)
+        out[name] = (takeover, reason, seen, last_speed, n_steps)
     differ = int((out["acc"][1] != out["noacc"][1]).sum())
     keys = ["ROLLOUT_LENGTH", "ST_TEST_ROLLOUTS", "COMBINATION_MIN_DISTANCE", "STOP_X", "TICK_LENGTH"]
     np.savez_compressed(os.path.join(HERE, "golden_combined_acc.npz"), ego=ego, k_count=k, other_x=ox, other_v=ov,
                         takeover=out["acc"][0], reason=out["acc"][1], saw_nonzero_acc=out["acc"][2], reason_without_acc_term=out["noacc"][1],
+                        selected_speed=out["acc"][3], rollout_steps=out["acc"][4], selected_speed_without_acc_term=out["noacc"][3],
                         setting_keys=np.array(keys), setting_vals=np.array([float(getattr(S, q)) for q in keys]),
                         flags=np.array([int(S.CHECK_ROLLOUT_CRASH), int(S.LIMIT_DQN_SPEED), int(S.TEST_ROLLOUT_STATE), int(S.TEST_ST_STRICTLY_BETTER)]))
-    print("combined acc: %d states, reasons %s; policy saw non-zero accelerations in %d states; decisions differ from the acceleration-blind policy in %d"
-          % (len(k), np.bincount(out["acc"][1], minlength=4).tolist(), int(out["acc"][2].sum()), differ))
+    print("combined acc: %d states, reasons %s; policy saw non-zero accelerations in %d states; decisions differ from the acceleration-blind policy in %d, last selected speed in %d"
+          % (len(k), np.bincount(out["acc"][1], minlength=4).tolist(), int(out["acc"][2].sum()), differ, int((out["acc"][3] != out["noacc"][3]).sum())))
 
 
 if __name__ == "__main__":
