@@ -6,6 +6,7 @@
  * the reference checkout jlubars/RL-MPC-LaneMerging):
  *
  *   stmpc_solve_grid          <- st_cy.solve_s_t_path_fast           st_cy.pyx:315-399 (call site st.py:740-746)
+ *   stmpc_solve_grid_no_jerk  <- st_cy.solve_s_t_path_no_jerk_fast / _djikstra   st_cy.pyx:96-312 (call site st.py:751)
  *   stmpc_build_grid          <- st.find_s_t_obstacles_from_state    st.py:25-70
  *   stmpc_solve_batch[_device]<- st.get_appropriate_base_st_path_and_obstacles (st.py:726-754) applied to N
  *                                independent HighwayState's (prediction.py:9-20), plus the path-distance probe of
@@ -163,6 +164,17 @@ int stmpc_solve_grid(stmpc_ctx *ctx, const uint8_t *obstacles, const double *s_v
                      double positive_acceleration_limit, double negative_jerk_limit,
                      double positive_jerk_limit, double min_allowed_distance,
                      double *s_sequence_out);
+
+/*
+ * The reference's two non-production solvers on materialised grids (HOST pointers), same grid arguments as stmpc_solve_grid:
+ *   variant 0 <- st_cy.solve_s_t_path_no_jerk_fast      st_cy.pyx:209-312   (node = (t, s))
+ *   variant 1 <- st_cy.solve_s_t_path_no_jerk_djikstra  st_cy.pyx:96-206    (node = (t, s, s_prev); the USE_FAST_ST_SOLVER = False
+ *                                                                           dispatch of st.py:749-753; needs H*S*S <= 2^28)
+ * Both use the constants compiled into the reference's st_cy module (st_cy.pyx:21-31), not Settings.
+ */
+int stmpc_solve_grid_no_jerk(stmpc_ctx *ctx, int variant, const uint8_t *obstacles, const double *s_values, int S,
+                             const double *t_values, int H, double ego_start_speed, const double *distances,
+                             double *s_sequence_out);
 
 /*
  * st.find_s_t_obstacles_from_state for one state (HOST pointers): fills

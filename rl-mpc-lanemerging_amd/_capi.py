@@ -76,7 +76,7 @@ EXPORTS = (
     "stmpc_num_t", "stmpc_path_mean_abs_jerk", "stmpc_solve_batch_device", "stmpc_solve_batch", "stmpc_get_stats",
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
-    "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state",
+    "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
 )
 
 QP_NMAX = 64        # STMPC_QP_NMAX
@@ -123,6 +123,7 @@ def load():
     lib.stmpc_solve_batch.argtypes = [vp, pp, C.c_int, C.c_int, dp, ip, dp, dp, ip, ip, dp, dp, ip]
     lib.stmpc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.stmpc_solve_grid.argtypes = [vp, u8p, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp] + [C.c_double] * 11 + [dp]
+    lib.stmpc_solve_grid_no_jerk.argtypes = [vp, C.c_int, u8p, dp, C.c_int, dp, C.c_int, C.c_double, dp, dp]
     lib.stmpc_build_grid.argtypes = [vp, pp, dp, C.c_int, dp, dp, u8p, dp, dp, dp]
     lib.stmpc_predict_batch.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
                                         dp, dp, dp, ip, dp]
@@ -163,6 +164,10 @@ def num_s(params, start_s):
 
 def num_t(params):
     return load().stmpc_num_t(C.byref(params))
+
+
+def path_mean_abs_jerk(seq, v0, a0, dt):
+    return load().stmpc_path_mean_abs_jerk(_dptr(seq), int(seq.size), float(v0), float(a0), float(dt))
 
 
 def backend_info():
@@ -307,6 +312,18 @@ class Context:
         self._chk(self._lib.stmpc_solve_grid(self._h, _u8ptr(ob), _dptr(sv), S, _dptr(tv), H, float(v0), float(a0),
                                              _dptr(di), *[float(x) for x in tunables11], _dptr(out)))
         return out
+
+    def solve_grid_no_jerk(self, variant, obstacles, s_values, t_values, v0, distances):
+        """variant 0 = st_cy.solve_s_t_path_no_jerk_fast, 1 = st_cy.solve_s_t_path_no_jerk_djikstra."""
+        ob = np.ascontiguousarray(obstacles).view(np.uint8)
+        sv = np.ascontiguousarray(s_values, dtype=np.float64)
+        tv = np.ascontiguousarray(t_values, dtype=np.float64)
+        di = np.ascontiguousarray(distances, dtype=np.float64)
+        if ob.shape != (tv.size, sv.size) or di.shape != ob.shape:
+            raise ValueError("obstacles / distances must be [num_t, num_s]")
+        seq = np.zeros(tv.size)
+        self._chk(self._lib.stmpc_solve_grid_no_jerk(self._h, int(variant), _u8ptr(ob), _dptr(sv), sv.size, _dptr(tv), tv.size, float(v0), _dptr(di), _dptr(seq)))
+        return seq
 
     def build_grid(self, params, state5, other_x, other_v):
         state5 = np.ascontiguousarray(state5, dtype=np.float64)

@@ -7,7 +7,6 @@ reference's ``Settings`` (RL training, logging, SUMO) is outside this package's 
 the JSON file is set as a class attribute, so the shipped experiment configs
 (``configs/*.json``) load unchanged.
 """
-import inspect
 import json
 
 
@@ -56,18 +55,17 @@ class Settings:
 
     @classmethod
     def export_settings(cls):
-        return {x[0]: x[1] for x in inspect.getmembers(cls, lambda m: not inspect.isroutine(m))
-                if not x[0].startswith('__')}
+        """All flags as a dict (the reference's ``Settings.export_settings``, config.py:157-159)."""
+        return {name: value for name, value in vars(cls).items()
+                if not name.startswith("_") and not isinstance(value, (classmethod, staticmethod)) and not callable(value)}
 
     @classmethod
     def load_from_file(cls, filename):
-        with open(filename, 'rb') as file:
-            contents = json.load(file)
-        for item in contents:
-            value = contents[item]
-            if isinstance(value, dict):
-                value = {int(x): value[x] for x in value}
-            setattr(cls, item, value)
+        """Every key of the JSON file becomes a class attribute (config.py:161-170); JSON objects get integer keys, as the
+        reference's per-level tables need."""
+        with open(filename, "r", encoding="utf-8") as fh:
+            for key, value in json.load(fh).items():
+                setattr(cls, key, {int(k): v for k, v in value.items()} if isinstance(value, dict) else value)
 
     @classmethod
     def snapshot(cls):

@@ -4,6 +4,7 @@
 #include "stmpc_kernels.hpp"
 #include "stmpc_ff_kernels.hpp"
 #include "stmpc_cc_kernels.hpp"
+#include "stmpc_nj_kernels.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -1118,6 +1119,52 @@ int stmpc_combined_read_state(stmpc_ctx *c, int N, int32_t *live, int32_t *hist_
         HIPCHK(hipMemcpy(&e, c->cc_err.p, 4, hipMemcpyDeviceToHost));
         if (e) return fail(STMPC_EINVAL, "finer_fit: a fine grid longer than STMPC_QP_NMAX samples is not supported");
     }
+    return STMPC_OK;
+}
+
+int stmpc_solve_grid_no_jerk(stmpc_ctx *c, int variant, const uint8_t *obstacles, const double *s_values, int S, const double *t_values,
+                             int H, double ego_start_speed, const double *distances, double *s_sequence_out) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (variant != 0 && variant != 1) return fail(STMPC_EINVAL, "variant must be 0 (no_jerk_fast) or 1 (no_jerk_djikstra)");
+    if (!obstacles || !s_values || !t_values || !distances || !s_sequence_out) return fail(STMPC_EINVAL, "NULL host pointer");
+    if (H < 2 || H > STMPC_H_LIMIT) return fail(STMPC_EINVAL, "num_t must be in [2, 64]");
+    if (S < 2 || S > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "num_s must be in [2, 65000]");
+    if (variant == 1 && (size_t)H * S * S > ((size_t)1 << 28)) return fail(STMPC_EINVAL, "no_jerk_djikstra keeps H*S*S node flags: lattice too large (H*S*S > 2^28)");
+    if (t_values[1] - t_values[0] == 0.0) return fail(STMPC_EINVAL, "float division by zero (delta_t == 0)");
+    if (s_values[1] - s_values[0] == 0.0) return fail(STMPC_EINVAL, "float division by zero (delta_s == 0)");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    const size_t cells = (size_t)H * S, states = variant ? cells * S : cells;
+    size_t cap = states * 8;
+    if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
+    if (cap > ((size_t)1 << 25)) cap = (size_t)1 << 25;               // 32 M entries = 768 MB at most
+    if ((rc = c->s_misc0.ensure(cells))) return rc;
+    if ((rc = c->s_misc1.ensure(cells * 8))) return rc;
+    if ((rc = c->s_misc2.ensure((size_t)S * 8))) return rc;
+    if ((rc = c->s_misc3.ensure((size_t)H * 8 + 16))) return rc;
+    if ((rc = c->s_pd.ensure(states))) return rc;
+    if ((rc = c->s_path.ensure(states * 4))) return rc;
+    if ((rc = c->gscratch.ensure(cap * sizeof(NjItem)))) return rc;
+    HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->s_misc2.p, s_values, (size_t)S * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->s_pd.p, 0, states));
+    HIPCHK(hipMemset(c->s_path.p, 0, states * 4));
+    NjArgs a;
+    memset(&a, 0, sizeof a);
+    a.triple = variant; a.S = S; a.H = H; a.v0 = ego_start_speed;
+    a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
+    a.dt = t_values[1] - t_values[0];
+    a.enc = c->s_pd.as<uint8_t>(); a.prev = c->s_path.as<int>(); a.heap = c->gscratch.as<NjItem>(); a.cap = cap;
+    a.s_sequence = c->s_misc3.as<double>(); a.status = (int *)(c->s_misc3.as<double>() + H);
+    hipLaunchKernelGGL(k_nojerk, dim3(1), dim3(64), 0, nullptr, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    int status = 0;
+    HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&status, (char *)c->s_misc3.p + (size_t)H * 8, 4, hipMemcpyDeviceToHost));
+    if (status == 1) return fail(STMPC_ENOMEM, "no-jerk solver: heap capacity exceeded");
+    if (status == 2) return fail(STMPC_EINVAL, "index out of bounds: the first layer's reachable cells leave the grid (IndexError in the reference)");
     return STMPC_OK;
 }
 

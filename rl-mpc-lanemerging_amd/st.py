@@ -111,10 +111,22 @@ def get_appropriate_base_st_path_and_obstacles(state):
         state, Settings.FUTURE_S, Settings.S_DISCRETIZATION, Settings.T_DISCRETIZATION, Settings.FUTURE_T,
         Settings.START_UNCERTAINTY, Settings.UNCERTAINTY_PER_SECOND)
     if not Settings.USE_FAST_ST_SOLVER:
-        raise NotImplementedError("only the production solver (USE_FAST_ST_SOLVER=True, st.py:738-746) is built; "
-                                  "the no-jerk variants (st_cy.pyx:96,209) are SURVEY row f4")
+        # st.py:749-753: the (t, s, s_prev) search on the materialised grids, with the constants compiled into st_cy
+        s_sequence = solve_s_t_path_no_jerk_djikstra(obstacles, s_values, t_values, ego_speed, distances)
+        return s_sequence, obstacles, s_values, t_values, distances
     seqs, _ = solve_states([state])
     return seqs[0], obstacles, s_values, t_values, distances
+
+
+def solve_s_t_path_no_jerk_fast(obstacles, s_values, t_values, ego_start_speed, distances):
+    """st_cy.solve_s_t_path_no_jerk_fast (st_cy.pyx:209-312) on materialised grids: returns the s sequence, 0.0 past the deepest layer."""
+    return _capi.default_context().solve_grid_no_jerk(0, obstacles, s_values, t_values, ego_start_speed, distances)
+
+
+def solve_s_t_path_no_jerk_djikstra(obstacles, s_values, t_values, ego_start_speed, distances):
+    """st_cy.solve_s_t_path_no_jerk_djikstra (st_cy.pyx:96-206): the search over (t, s, s_prev) nodes.  It keeps num_t * num_s**2
+    node flags (the reference allocates that as well); lattices beyond 2**28 of them are rejected."""
+    return _capi.default_context().solve_grid_no_jerk(1, obstacles, s_values, t_values, ego_start_speed, distances)
 
 
 def finer_fit(s_sequence, delta_t, coarse_delta_t, start_speed, start_acceleration, before_after_cars=None):
@@ -138,7 +150,9 @@ def finer_fit(s_sequence, delta_t, coarse_delta_t, start_speed, start_accelerati
 def do_st_control(state):
     """st.py:757-783.  Returns the commanded speed and forwards it to ``control.set_ego_speed``."""
     ego, k_count, ox, ov = pack_states([state])
-    res = _capi.default_context().st_control_batch(_params_from_settings(), Settings.TICK_LENGTH, ego, k_count, ox, ov)
+    res = _capi.default_context().st_control_batch(_params_from_settings(), Settings.TICK_LENGTH, ego, k_count, ox, ov, want_paths=True)
+    if res["fine_len"][0] < 0:
+        raise ValueError("finer_fit: more than %d fine samples are not supported" % _capi.QP_NMAX)
     if res["best_t"][0] != _capi.num_t(_params_from_settings()) - 1:
         print("ST Solver finds crash inevitable")              # st.py:765-766
     speed = float(res["speed"][0])
@@ -152,7 +166,9 @@ def do_st_control_batch(states, params=None, ctx=None):
     params = params or _params_from_settings()
     ctx = ctx or _capi.default_context()
     ego, k_count, ox, ov = pack_states(states)
-    res = ctx.st_control_batch(params, Settings.TICK_LENGTH, ego, k_count, ox, ov)
+    res = ctx.st_control_batch(params, Settings.TICK_LENGTH, ego, k_count, ox, ov, want_paths=True)
+    if (res["fine_len"] < 0).any():
+        raise ValueError("finer_fit: more than %d fine samples are not supported" % _capi.QP_NMAX)
     return res["speed"], res["best_t"]
 
 
@@ -166,18 +182,8 @@ test_guaranteed_crash_from_state.__test__ = False   # not a pytest test
 
 
 def get_path_mean_abs_jerk(s_sequence, ego_start_speed, ego_start_acceleration, delta_t):
-    # st.py:274-288
-    prev_a = ego_start_acceleration
-    prev_v = ego_start_speed
-    path_cost = 0
-    for i, s in enumerate(s_sequence):
-        if i == 0:
-            continue
-        s_1 = s_sequence[i - 1]
-        v = (s - s_1) / delta_t
-        a = (v - prev_v) / delta_t
-        j = (a - prev_a) / delta_t
-        prev_v = v
-        prev_a = a
-        path_cost += abs(j)
-    return path_cost / (len(s_sequence) - 1)
+    """st.py:274-288: mean |jerk| of a path given the start speed and acceleration (the library's host helper, same operations)."""
+    seq = np.ascontiguousarray(s_sequence, dtype=np.float64)
+    if seq.size < 2:
+        raise ZeroDivisionError("division by zero")        # the reference divides by len - 1
+    return _capi.path_mean_abs_jerk(seq, ego_start_speed, ego_start_acceleration, delta_t)
