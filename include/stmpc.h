@@ -279,6 +279,37 @@ int stmpc_combined_read_state(stmpc_ctx *ctx, int N, int32_t *live, int32_t *his
                               double *rollout_s, int32_t *have_test, double *test_ego4, double *test_ox, double *test_ov,
                               int32_t *probe_crash, double *st_speed, double *fine, int32_t *fine_len);
 
+/*
+ * Batched SUMO-free merge episodes: stands in for control.run_episode / control.step (control.py:207-340) so that whole
+ * episodes can be run for N environments in lock-step on the device.  The world is the planner's own model (ego motion
+ * prediction.py:46-59, follower rule prediction.py:75-97, vehicles entering the highway as control.py:215-226 adds them), NOT
+ * SUMO's: episode statistics compare with the reference's reports as distributions only.
+ *   stmpc_sim_init_device   traffic in its stationary state, ego at the ramp start with control.get_ego_start_speed's draw
+ *   stmpc_sim_view_device   planner inputs of every environment (the layout stmpc_solve_batch_device takes; vehicles within the
+ *                           sensor radius, front to back; other_a may be NULL)
+ *   stmpc_sim_step_device   one tick with the commanded speeds (limited by the vehicle's acceleration limits); finished environments idle
+ *   stmpc_sim_read          host copies: status [N] (0 running, 1 arrived = "merged", 2 crashed, 3 out of time), ticks [N], acc [N][8] = sum of
+ *                           speeds, max speed, sum |jerk|, (internal), samples, closest distance past CRASH_MIN_S, sum and count of those
+ *                           distances, and ego [N][4]
+ */
+typedef struct stmpc_sim_cfg {
+    double tick_length;              /* Settings.TICK_LENGTH */
+    double other_car_speed;          /* Settings.OTHER_CAR_SPEED */
+    double base_traffic_interval;    /* Settings.BASE_TRAFFIC_INTERVAL */
+    double spawn_x, despawn_x;       /* ends of the highway edges: -250, 100 (merge.net.xml:45-49) */
+    double ego_start_x, ego_start_y; /* departPos 40 on the ramp (control.py:42) */
+    double arrive_x;                 /* arrivalPos 50 on highwayahead = x 51.5 (control.py:42) */
+    double sensor_radius;            /* Settings.SENSOR_RADIUS */
+    double start_speed, start_speed_std, min_start_speed, max_start_speed;   /* control.py:198-204 */
+    int32_t vary_traffic_start_times, randomize_start_speed, max_ticks;
+    uint64_t seed;
+} stmpc_sim_cfg;
+int stmpc_sim_init_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, void *stream);
+int stmpc_sim_view_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, int Kmax, double *d_ego5, int32_t *d_k_count,
+                          double *d_other_x, double *d_other_v, double *d_other_a, void *stream);
+int stmpc_sim_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_sim_cfg *cfg, int N, const double *d_cmd_speed, void *stream);
+int stmpc_sim_read(stmpc_ctx *ctx, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4);
+
 /* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
  * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b) HOST pointers. */
 int stmpc_probe_arith(stmpc_ctx *ctx, int op, const double *a, const double *b, double *out, int n);

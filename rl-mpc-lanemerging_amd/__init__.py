@@ -14,7 +14,7 @@ __version__ = "0.1.0"
 
 def __getattr__(name):
     # the modules that need libstmpc.so are imported lazily so that `build` is usable before the first build
-    if name in ("_capi", "st", "prediction", "sharding", "combined"):
+    if name in ("_capi", "st", "prediction", "sharding", "combined", "combined_bench", "episodes"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -65,6 +65,15 @@ class CombinedCfg(C.Structure):
                    remember_last_choice=int(bool(getattr(S, "REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED", False))))
 
 
+class SimCfg(C.Structure):
+    """``stmpc_sim_cfg`` (include/stmpc.h): scenario constants of the batched SUMO-free episode runner."""
+    _fields_ = [("tick_length", C.c_double), ("other_car_speed", C.c_double), ("base_traffic_interval", C.c_double), ("spawn_x", C.c_double),
+                ("despawn_x", C.c_double), ("ego_start_x", C.c_double), ("ego_start_y", C.c_double), ("arrive_x", C.c_double),
+                ("sensor_radius", C.c_double), ("start_speed", C.c_double), ("start_speed_std", C.c_double), ("min_start_speed", C.c_double),
+                ("max_start_speed", C.c_double), ("vary_traffic_start_times", C.c_int32), ("randomize_start_speed", C.c_int32),
+                ("max_ticks", C.c_int32), ("seed", C.c_uint64)]
+
+
 class ProfileTotals(C.Structure):
     _fields_ = [("launches", C.c_int64), ("episodes", C.c_int64), ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double)]
 
@@ -77,6 +86,7 @@ EXPORTS = (
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
     "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
+    "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read",
 )
 
 QP_NMAX = 64        # STMPC_QP_NMAX
@@ -130,6 +140,11 @@ def load():
     cp = C.POINTER(CombinedCfg)
     lib.stmpc_rollout_step_device.argtypes = [vp, pp, cp, C.c_int, C.c_int, C.c_int] + [vp] * 7 + [vp]
     lib.stmpc_combined_decide_device.argtypes = [vp, pp, cp, C.c_int, C.c_int] + [vp] * 12 + [vp]
+    sp = C.POINTER(SimCfg)
+    lib.stmpc_sim_init_device.argtypes = [vp, sp, C.c_int, vp]
+    lib.stmpc_sim_view_device.argtypes = [vp, sp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.stmpc_sim_step_device.argtypes = [vp, pp, sp, C.c_int, vp, vp]
+    lib.stmpc_sim_read.argtypes = [vp, C.c_int, ip, ip, dp, dp]
     lib.stmpc_combined_read_state.argtypes = [vp, C.c_int, ip, ip, ip, dp, dp, ip, dp, dp, dp, ip, dp, dp, ip]
     lib.stmpc_probe_arith.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.stmpc_profile.argtypes = [vp, C.c_int, C.POINTER(ProfileTotals)]
@@ -371,6 +386,22 @@ class Context:
         self._chk(self._lib.stmpc_combined_decide_device(self._h, C.byref(params), C.byref(cfg), int(N), int(Kmax), d_ego5_start, d_k, d_ox_start,
                                                          d_ov_start, d_cur_ego4, d_cur_ox, d_cur_ov, d_first_action, d_last_choice_rl,
                                                          d_takeover, d_reason, d_speed, stream))
+
+    # -- batched episode simulator --------------------------------------------------------------
+    def sim_init(self, cfg, N, stream=0):
+        self._chk(self._lib.stmpc_sim_init_device(self._h, C.byref(cfg), int(N), stream))
+
+    def sim_view(self, cfg, N, Kmax, d_ego5, d_k, d_ox, d_ov, d_oa=0, stream=0):
+        self._chk(self._lib.stmpc_sim_view_device(self._h, C.byref(cfg), int(N), int(Kmax), d_ego5, d_k, d_ox, d_ov, d_oa, stream))
+
+    def sim_step(self, params, cfg, N, d_cmd_speed, stream=0):
+        self._chk(self._lib.stmpc_sim_step_device(self._h, C.byref(params), C.byref(cfg), int(N), d_cmd_speed, stream))
+
+    def sim_read(self, N):
+        status, ticks = np.zeros(N, np.int32), np.zeros(N, np.int32)
+        acc, ego4 = np.zeros((N, 8)), np.zeros((N, 4))
+        self._chk(self._lib.stmpc_sim_read(self._h, int(N), _iptr(status), _iptr(ticks), _dptr(acc), _dptr(ego4)))
+        return status, ticks, acc, ego4
 
     def combined_read_state(self, N, Kmax, rollout_length, after_decide=True):
         """Host copies of the rollout bookkeeping (and, after the decision, of the probe / controller results)."""

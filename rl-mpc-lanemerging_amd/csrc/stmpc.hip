@@ -76,6 +76,9 @@ struct stmpc_ctx {
     DevBuf cc_live, cc_hist_len, cc_crash_pred, cc_have_test, cc_sel, cc_rollout_s, cc_test_ego, cc_test_ox, cc_test_ov, cc_probe_ego, cc_probe_ox, cc_probe_ov,
         cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err;
     int cc_N = 0, cc_K = 0, cc_R = 0;
+    // batched episode simulator (stmpc_sim_*)
+    DevBuf sim_ego, sim_nveh, sim_vx, sim_vv, sim_va, sim_vc, sim_delay, sim_status, sim_ticks, sim_rng, sim_acc;
+    int sim_N = 0;
     DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
@@ -228,7 +231,8 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
                      &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
-                     &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
+                     &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
+                     &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1165,6 +1169,92 @@ int stmpc_solve_grid_no_jerk(stmpc_ctx *c, int variant, const uint8_t *obstacles
     HIPCHK(hipMemcpy(&status, (char *)c->s_misc3.p + (size_t)H * 8, 4, hipMemcpyDeviceToHost));
     if (status == 1) return fail(STMPC_ENOMEM, "no-jerk solver: heap capacity exceeded");
     if (status == 2) return fail(STMPC_EINVAL, "index out of bounds: the first layer's reachable cells leave the grid (IndexError in the reference)");
+    return STMPC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int make_simcfg(const stmpc_sim_cfg *g, sim::Cfg *c) {
+    if (!g) return fail(STMPC_EINVAL, "sim cfg is NULL");
+    if (!(g->tick_length > 0) || !(g->other_car_speed > 0) || !(g->base_traffic_interval > 0)) return fail(STMPC_EINVAL, "tick_length, other_car_speed and base_traffic_interval must be positive");
+    memset(c, 0, sizeof *c);
+    c->tick = g->tick_length; c->other_speed = g->other_car_speed; c->base_interval = g->base_traffic_interval;
+    c->spawn_x = g->spawn_x; c->despawn_x = g->despawn_x; c->ego_start_x = g->ego_start_x; c->ego_start_y = g->ego_start_y; c->arrive_x = g->arrive_x;
+    c->sensor_radius = g->sensor_radius; c->start_speed = g->start_speed; c->start_speed_std = g->start_speed_std;
+    c->min_start_speed = g->min_start_speed; c->max_start_speed = g->max_start_speed;
+    c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->seed = g->seed;
+    return STMPC_OK;
+}
+sim::State sim_state(stmpc_ctx *c) {
+    return sim::State{c->sim_ego.as<double>(), c->sim_nveh.as<int>(), c->sim_vx.as<double>(), c->sim_vv.as<double>(), c->sim_va.as<double>(), c->sim_vc.as<double>(), c->sim_delay.as<double>(),
+                      c->sim_status.as<int>(), c->sim_ticks.as<int>(), c->sim_rng.as<unsigned>(), c->sim_acc.as<double>()};
+}
+}  // namespace
+
+extern "C" {
+
+int stmpc_sim_init_device(stmpc_ctx *c, const stmpc_sim_cfg *g, int N, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N < 1) return fail(STMPC_EINVAL, "N must be positive");
+    sim::Cfg sc;
+    int rc = make_simcfg(g, &sc);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t KS = sim::KS;
+    if ((rc = c->sim_ego.ensure((size_t)N * 4 * 8))) return rc;
+    if ((rc = c->sim_nveh.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->sim_vx.ensure((size_t)N * KS * 8))) return rc;
+    if ((rc = c->sim_vv.ensure((size_t)N * KS * 8))) return rc;
+    if ((rc = c->sim_va.ensure((size_t)N * KS * 8))) return rc;
+    if ((rc = c->sim_vc.ensure((size_t)N * KS * 8))) return rc;
+    if ((rc = c->sim_delay.ensure((size_t)N * 8))) return rc;
+    if ((rc = c->sim_status.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->sim_ticks.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->sim_rng.ensure((size_t)N * 4))) return rc;
+    if ((rc = c->sim_acc.ensure((size_t)N * 8 * 8))) return rc;
+    c->sim_N = N;
+    hipLaunchKernelGGL(sim::k_sim_init, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sc, N, sim_state(c));
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_sim_view_device(stmpc_ctx *c, const stmpc_sim_cfg *g, int N, int Kmax, double *d_ego5, int32_t *d_k, double *d_ox, double *d_ov, double *d_oa, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N != c->sim_N || Kmax < 1 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N does not match stmpc_sim_init_device, or Kmax out of range");
+    if (!d_ego5 || !d_k || !d_ox || !d_ov) return fail(STMPC_EINVAL, "NULL device pointer");
+    sim::Cfg sc;
+    int rc = make_simcfg(g, &sc);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(sim::k_sim_view, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sc, N, Kmax, sim_state(c), d_ego5, d_k, d_ox, d_ov, d_oa);
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_sim_step_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_sim_cfg *g, int N, const double *d_cmd_speed, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N != c->sim_N || !d_cmd_speed) return fail(STMPC_EINVAL, "N does not match stmpc_sim_init_device, or NULL device pointer");
+    sim::Cfg sc;
+    DevP dp;
+    int rc = make_simcfg(g, &sc);
+    if (rc) return rc;
+    if ((rc = make_devp(p, &dp))) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(sim::k_sim_step, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, dp, sc, N, sim_state(c), d_cmd_speed, p->crash_min_s);
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_sim_read(stmpc_ctx *c, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N != c->sim_N) return fail(STMPC_EINVAL, "N does not match stmpc_sim_init_device");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (status) HIPCHK(hipMemcpy(status, c->sim_status.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (ticks) HIPCHK(hipMemcpy(ticks, c->sim_ticks.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (acc8) HIPCHK(hipMemcpy(acc8, c->sim_acc.p, (size_t)N * 64, hipMemcpyDeviceToHost));
+    if (ego4) HIPCHK(hipMemcpy(ego4, c->sim_ego.p, (size_t)N * 32, hipMemcpyDeviceToHost));
     return STMPC_OK;
 }
 

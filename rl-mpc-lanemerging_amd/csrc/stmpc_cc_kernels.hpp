@@ -146,4 +146,162 @@ __global__ void __launch_bounds__(64) k_cc_decide(CCfg c, int N, const double *_
     speed_out[e] = speed;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SUMO-free batched merge episodes (stands in for control.run_episode / control.step,
+// control.py:215-340).  The world IS the planner's own model: the ego moves as prediction.py:46-59 says, the highway
+// vehicles follow prediction.py:75-97 (constant speed, braking behind a slower leader within 30 m, reacting to the ego once
+// it has merged), vehicles enter the highway as control.step adds them (control.py:215-226) and leave at its end.  Nothing
+// here reproduces SUMO's Krauss model, so episode statistics are comparable with the reference's reports only as
+// distributions -- and are labelled so.  One thread per environment; vehicles live in [N][KS] arrays, front to back.
+namespace sim {
+constexpr int KS = 64;             // vehicle slots per environment
+struct Cfg {
+    double tick, other_speed, base_interval, spawn_x, despawn_x, ego_start_x, ego_start_y, arrive_x, sensor_radius;
+    double start_speed, start_speed_std, min_start_speed, max_start_speed;
+    int vary_interval, randomize_start_speed, max_ticks;
+    unsigned long long seed;
+};
+struct State {                     // device arrays
+    double *ego4;                  // [N][4] x, y, v, a
+    int *nveh;                     // [N]
+    double *vx, *vv, *va, *vc;     // [N][KS] position, speed, acceleration, cruise speed of each vehicle
+    double *delay;                 // [N] time to the next highway vehicle
+    int *status;                   // [N] 0 running, 1 arrived ("merged"), 2 crashed, 3 out of time
+    int *ticks;                    // [N] controlled ticks so far
+    unsigned *rng;                 // [N] draws so far
+    double *acc;                   // [N][8]: sum speed, max speed, sum |jerk|, previous acceleration, samples, min gap (s > CRASH_MIN_S), sum gap, gap samples
+};
+__device__ __forceinline__ double uniform01(unsigned long long seed, int env, unsigned &ctr) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)env * 0x100000001ull + (unsigned long long)(ctr++) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;      // splitmix64
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+// SUMO's vType "normal" (merge.rou.xml:28-29, maxSpeed set to OTHER_CAR_SPEED by sumo.py:58): each vehicle cruises at
+// OTHER_CAR_SPEED * speedFactor, speedFactor ~ normc(1.0, 0.1) clipped to [0.2, 2]; a vehicle is inserted only when the one
+// ahead leaves the IDM desired gap minGap + v * tau + length = 2.5 + v + 5 free (SUMO postpones unsafe insertions).
+__device__ __forceinline__ double cruise_speed(const Cfg &c, int env, unsigned &ctr) {
+    const double u1 = uniform01(c.seed, env, ctr), u2 = uniform01(c.seed, env, ctr);
+    double f = 1.0 + 0.1 * sqrt(-2.0 * log(u1 > 1e-300 ? u1 : 1e-300)) * cos(6.283185307179586 * u2);
+    f = f < 0.2 ? 0.2 : (f > 2.0 ? 2.0 : f);
+    return c.other_speed * f;
+}
+__global__ void __launch_bounds__(64) k_sim_init(Cfg c, int N, State s) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    unsigned ctr = 0;
+    // highway traffic in its stationary state (what the reference gets from 20 s of warm-up ticks, control.py:255-256)
+    int n = 0;
+    double x = c.despawn_x - c.other_speed * uniform01(c.seed, e, ctr) * (c.base_interval + (c.vary_interval ? 1.0 : 0.0));
+    const double min_gap = 2.5 + c.other_speed + 5.0;
+    while (x > c.spawn_x && n < KS) {
+        s.vx[(size_t)e * KS + n] = x; s.vv[(size_t)e * KS + n] = c.other_speed; s.va[(size_t)e * KS + n] = 0.0; s.vc[(size_t)e * KS + n] = cruise_speed(c, e, ctr); ++n;
+        const double step = c.other_speed * (c.base_interval + (c.vary_interval ? uniform01(c.seed, e, ctr) : 0.0));
+        x -= step > min_gap ? step : min_gap;
+    }
+    s.nveh[e] = n;
+    s.delay[e] = (x - c.spawn_x) / (c.other_speed > 0 ? -c.other_speed : -1.0);      // (x < spawn_x here: the next vehicle enters after that time)
+    double v0 = c.start_speed;                                                        // control.get_ego_start_speed, control.py:198-204
+    if (c.randomize_start_speed) {
+        const double u1 = uniform01(c.seed, e, ctr), u2 = uniform01(c.seed, e, ctr);
+        v0 = c.start_speed + c.start_speed_std * sqrt(-2.0 * log(u1 > 1e-300 ? u1 : 1e-300)) * cos(6.283185307179586 * u2);
+        v0 = v0 < c.min_start_speed ? c.min_start_speed : (v0 > c.max_start_speed ? c.max_start_speed : v0);
+    }
+    s.ego4[e * 4 + 0] = c.ego_start_x; s.ego4[e * 4 + 1] = c.ego_start_y; s.ego4[e * 4 + 2] = v0; s.ego4[e * 4 + 3] = 0.0;
+    s.status[e] = 0; s.ticks[e] = 0; s.rng[e] = ctr;
+    for (int q = 0; q < 8; ++q) s.acc[(size_t)e * 8 + q] = 0.0;
+    s.acc[(size_t)e * 8 + 5] = 1e300;
+}
+// The planner's view of each environment: the vehicles within the sensor radius, front to back, and the ego with its s coordinate.
+__global__ void __launch_bounds__(64) k_sim_view(Cfg c, int N, int Kmax, State s, double *ego5, int *k_count, double *ox, double *ov, double *oa) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const double ex = s.ego4[e * 4 + 0], ey = s.ego4[e * 4 + 1];
+    for (int q = 0; q < 4; ++q) ego5[(size_t)e * 5 + q] = s.ego4[e * 4 + q];
+    ego5[(size_t)e * 5 + 4] = dev_ego_s(ex, ey);
+    int k = 0;
+    const int n = s.nveh[e];
+    for (int i = 0; i < n && k < Kmax; ++i) {
+        const double x = s.vx[(size_t)e * KS + i];
+        if (fabs(x - ex) <= c.sensor_radius) { ox[(size_t)e * Kmax + k] = x; ov[(size_t)e * Kmax + k] = s.vv[(size_t)e * KS + i]; if (oa) oa[(size_t)e * Kmax + k] = s.va[(size_t)e * KS + i]; ++k; }
+    }
+    for (int i = k; i < Kmax; ++i) { ox[(size_t)e * Kmax + i] = 0.0; ov[(size_t)e * Kmax + i] = 0.0; if (oa) oa[(size_t)e * Kmax + i] = 0.0; }
+    k_count[e] = k;
+}
+// One simulator tick with the commanded ego speed.
+__global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, const double *__restrict__ cmd_speed, double crash_min_s) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || s.status[e] != 0) return;
+    const double dt = c.tick;
+    double cx = s.ego4[e * 4 + 0], cy = s.ego4[e * 4 + 1];
+    const double v_prev = s.ego4[e * 4 + 2];
+    double sel = cmd_speed[e];
+    if (!(sel == sel)) sel = v_prev;                                              // (a NaN command keeps the speed)
+    // the vehicle cannot change its speed faster than its acceleration limits (SUMO vType accel 4.5 / decel 6.0, merge.rou.xml:2)
+    const double hi = v_prev + p.a_max * dt, lo = v_prev + p.a_min * dt;
+    sel = sel > hi ? hi : (sel < lo ? lo : sel);
+    sel = sel < 0 ? 0 : (sel > p.v_max ? p.v_max : sel);
+    // ego motion, prediction.py:46-59
+    double px, py;
+    if (cx < 1.5) {
+        double d0 = 1.5 - cx, d1 = -1.5 - cy;
+        const double nrm = sqrt(__builtin_fma(d1, d1, d0 * d0));
+        d0 /= nrm; d1 /= nrm;
+        px = cx + d0 * (sel * dt); py = cy + d1 * (sel * dt);
+        if (py < -1.6) py = -1.6;
+    } else { py = cy; px = cx + sel * dt; }
+    const double acc_ego = (sel - v_prev) / dt;
+    const double es = dev_ego_s(px, py);
+    const bool can_crash = es > p.crash_thr, merged = es > p.react_thr;
+    // highway vehicles, prediction.py:75-97
+    const int n = s.nveh[e];
+    double last_x = __builtin_inf(), last_speed = 0.0;
+    bool enc = false, crashed = false;
+    double gap = 100.0;
+    for (int i = 0; i < n; ++i) {
+        const double ox_ = s.vx[(size_t)e * KS + i], ov_ = s.vv[(size_t)e * KS + i];
+        if (ox_ < px && !enc) { enc = true; if (merged) { last_x = px; last_speed = sel; } }
+        const double sd = last_speed - ov_, xd = last_x - ox_;
+        double a_ = 0.0, nv = ov_;
+        if (sd < 0 && xd < p.follow_gap) { a_ = sd > p.max_pred_decel ? sd : p.max_pred_decel; nv = ov_ + a_ * dt; }
+        else {                                                                    // free road: towards the vehicle's own cruise speed
+            const double vc_ = s.vc[(size_t)e * KS + i];
+            if (ov_ < vc_) { a_ = (vc_ - ov_) / dt; a_ = a_ > 2.6 ? 2.6 : a_; nv = ov_ + a_ * dt; }
+            else if (ov_ > vc_) { a_ = (vc_ - ov_) / dt; a_ = a_ < -2.0 ? -2.0 : a_; nv = ov_ + a_ * dt; }
+        }
+        const double nx = ox_ + nv * dt;
+        last_x = nx; last_speed = nv;
+        s.vx[(size_t)e * KS + i] = nx; s.vv[(size_t)e * KS + i] = nv; s.va[(size_t)e * KS + i] = a_;
+        const double d = fabs(nx - px);
+        if (d < p.car_length && can_crash) crashed = true;
+        gap = d < gap ? d : gap;
+    }
+    // vehicles leaving at the end of the highway (front of the list) and entering at its start, control.py:215-226
+    int nn = n, drop = 0;
+    while (drop < nn && s.vx[(size_t)e * KS + drop] > c.despawn_x) ++drop;
+    if (drop) { for (int i = drop; i < nn; ++i) { s.vx[(size_t)e * KS + i - drop] = s.vx[(size_t)e * KS + i]; s.vv[(size_t)e * KS + i - drop] = s.vv[(size_t)e * KS + i]; s.va[(size_t)e * KS + i - drop] = s.va[(size_t)e * KS + i]; s.vc[(size_t)e * KS + i - drop] = s.vc[(size_t)e * KS + i]; } nn -= drop; }
+    double delay = s.delay[e];
+    unsigned ctr = s.rng[e];
+    if (delay <= 0) {
+        const bool room = nn == 0 || s.vx[(size_t)e * KS + nn - 1] - c.spawn_x >= 2.5 + c.other_speed + 5.0;       // SUMO postpones an unsafe insertion
+        if (room && nn < KS) {
+            s.vx[(size_t)e * KS + nn] = c.spawn_x; s.vv[(size_t)e * KS + nn] = c.other_speed; s.va[(size_t)e * KS + nn] = 0.0; s.vc[(size_t)e * KS + nn] = cruise_speed(c, e, ctr); ++nn;
+            delay = (c.vary_interval ? uniform01(c.seed, e, ctr) : 0.0) + c.base_interval;
+        }
+    }
+    delay -= dt;
+    s.delay[e] = delay; s.rng[e] = ctr; s.nveh[e] = nn;
+    s.ego4[e * 4 + 0] = px; s.ego4[e * 4 + 1] = py; s.ego4[e * 4 + 2] = sel; s.ego4[e * 4 + 3] = acc_ego;
+    // episode statistics, control.py:276-283 / stats.py:43-75
+    double *a = s.acc + (size_t)e * 8;
+    const int tk = s.ticks[e];
+    a[0] += sel; a[1] = sel > a[1] ? sel : a[1];
+    if (tk > 0) a[2] += fabs((acc_ego - a[3]) / dt);
+    a[3] = acc_ego; a[4] += 1.0;
+    if (es > crash_min_s) { a[5] = gap < a[5] ? gap : a[5]; a[6] += gap; a[7] += 1.0; }
+    s.ticks[e] = tk + 1;
+    if (crashed) s.status[e] = 2;
+    else if (px >= c.arrive_x) s.status[e] = 1;
+    else if (tk + 1 >= c.max_ticks) s.status[e] = 3;
+}
+}  // namespace sim
 }  // namespace stmpc

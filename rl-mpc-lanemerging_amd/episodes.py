@@ -1,0 +1,101 @@
+"""Batched SUMO-free merge episodes: the role of the reference's ``control.run_episode`` /
+``control.evaluate_control`` (control.py:207-395) and of the per-episode columns of ``stats.StatsAggregator``
+(stats.py:43-111), for N environments stepped in lock-step on one GPU.
+
+The world model is the planner's own (see ``stmpc_sim_*`` in include/stmpc.h), not SUMO: results are comparable with the
+reference's reported numbers (experiment_data/saved_data.csv) as DISTRIBUTIONS only.  Every tick is: planner view ->
+controller (``st.do_st_control`` for all environments in one launch, or the combined controller) -> world step; nothing but a
+periodic "all finished?" flag crosses to the host.
+"""
+import numpy as np
+
+from . import _capi, synth
+from .config import Settings
+
+# scenario constants of the reference's SUMO network and episode runner
+SPAWN_X, DESPAWN_X = -250.0, 100.0          # highwayrear starts at x = -250, highwayahead ends at x = 100 (merge.net.xml:45-49)
+EGO_START_ARC = 40.0                        # departPos = 40 on the ramp (control.py:42)
+ARRIVE_X = 1.5 + 50.0                       # arrivalPos = 50 on highwayahead (control.py:42)
+RAMP_START = (-250.47, 28.47)               # first point of lane ramp_0 (merge.net.xml:52)
+
+
+def ego_start_position():
+    """Point 40 m along the ramp from its start, on the straight line the predictor moves the ego along."""
+    x0, y0 = RAMP_START
+    d = np.hypot(-50.58 - x0, 1.71 - y0)
+    ux, uy = (-50.58 - x0) / d, (1.71 - y0) / d
+    return x0 + EGO_START_ARC * ux, y0 + EGO_START_ARC * uy
+
+
+def sim_cfg(seed=0, max_episode_length=100.0):
+    S = Settings
+    ex, ey = ego_start_position()
+    g = lambda name, default: getattr(S, name, default)
+    return _capi.SimCfg(tick_length=S.TICK_LENGTH, other_car_speed=g("OTHER_CAR_SPEED", 7.0), base_traffic_interval=g("BASE_TRAFFIC_INTERVAL", 1.2),
+                        spawn_x=SPAWN_X, despawn_x=DESPAWN_X, ego_start_x=ex, ego_start_y=ey, arrive_x=ARRIVE_X, sensor_radius=g("SENSOR_RADIUS", 125.0),
+                        start_speed=g("START_SPEED", 15.0), start_speed_std=g("START_SPEED_VARIANCE", 5.0), min_start_speed=g("MIN_START_SPEED", 5.0),
+                        max_start_speed=g("MAX_START_SPEED", 25.0), vary_traffic_start_times=int(bool(g("VARY_TRAFFIC_START_TIMES", True))),
+                        randomize_start_speed=int(bool(g("RANDOMIZE_START_SPEED", True))), max_ticks=int(max_episode_length / S.TICK_LENGTH), seed=int(seed))
+
+
+def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0, check_every=16):
+    """Run ``n`` merge episodes to the end; returns the per-episode columns of the reference's stats report
+    (``crashed``, ``merged``, ``mean_speed``, ``max_speed``, ``mean_abs_jerk``, ``closest_distance``, ``mean_closest_distance``,
+    ``time_taken``, ``time_to_merge`` (NaN unless merged)) plus ``ticks`` and ``percent_st`` (combined controller only).
+
+    controller: "st" = ``st.do_st_control`` every tick (TASK "ST"); "combined" = ``do_combined_control`` with ``policy``
+    (see ``combined.decide_batch_device``)."""
+    import torch
+    from . import combined
+    ctx = ctx or _capi.default_context()
+    params = _capi.Params.from_settings(Settings)
+    cfg = sim_cfg(seed, max_episode_length)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H = _capi.num_t(params)
+    d_ego5 = torch.zeros((n, 5), dtype=torch.float64, device=dev)
+    d_k = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ox = torch.zeros((n, kmax), dtype=torch.float64, device=dev)
+    d_ov = torch.zeros((n, kmax), dtype=torch.float64, device=dev)
+    d_path = torch.zeros((n, H), dtype=torch.int32, device=dev)
+    d_bt = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_cost = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_speed = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_fine = torch.zeros((n, _capi.QP_NMAX), dtype=torch.float64, device=dev)
+    d_fine_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    ccfg = _capi.CombinedCfg.from_settings(Settings) if controller == "combined" else None
+    takeovers = torch.zeros(n, dtype=torch.float64, device=dev)
+    controlled = torch.zeros(n, dtype=torch.float64, device=dev)
+    last_rl = torch.ones(n, dtype=torch.int32, device=dev)
+    ctx.sim_init(cfg, n)
+    for tick in range(cfg.max_ticks + 1):
+        ctx.sim_view(cfg, n, kmax, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr())
+        if controller == "st":
+            ctx.st_control_batch_device(params, Settings.TICK_LENGTH, n, kmax, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
+                                        d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_speed.data_ptr(), d_fine.data_ptr(), d_fine_len.data_ptr(), 0)
+            cmd = d_speed
+        else:
+            d = combined.decide_batch_device(ctx, params, ccfg, d_ego5, d_k, d_ox, d_ov, policy, last_rl)
+            cmd = d["speed"]
+            takeovers += d["takeover"].to(torch.float64)
+            controlled += 1.0
+            last_rl = (d["takeover"] == 0).to(torch.int32)
+        ctx.sim_step(params, cfg, n, cmd.data_ptr())
+        if tick % check_every == check_every - 1:
+            status, _, _, _ = ctx.sim_read(n)
+            if (status != 0).all():
+                break
+    status, ticks, acc, _ = ctx.sim_read(n)
+    samples = np.maximum(acc[:, 4], 1.0)
+    out = {"crashed": (status == 2).astype(np.float64), "merged": (status == 1).astype(np.float64), "timed_out": (status == 3).astype(np.float64),
+           "mean_speed": acc[:, 0] / samples, "max_speed": acc[:, 1], "mean_abs_jerk": acc[:, 2] / samples,
+           "closest_distance": np.where(acc[:, 7] > 0, acc[:, 5], np.nan), "mean_closest_distance": np.where(acc[:, 7] > 0, acc[:, 6] / np.maximum(acc[:, 7], 1.0), np.nan),
+           "time_taken": ticks * Settings.TICK_LENGTH, "ticks": ticks}
+    out["time_to_merge"] = np.where(status == 1, out["time_taken"], np.nan)
+    if controller == "combined":
+        out["percent_st"] = (takeovers / torch.clamp(controlled, min=1.0)).cpu().numpy()
+    return out
+
+
+def summary(stats):
+    """Column means as the reference's report rows hold them (stats.py:145-158)."""
+    return {k: float(np.nanmean(v)) for k, v in stats.items() if k != "ticks"}
