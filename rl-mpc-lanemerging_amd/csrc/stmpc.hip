@@ -71,7 +71,7 @@ struct stmpc_ctx {
     DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, proxy, order, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
-    DevBuf ckpt, resume_t, phase_prof;
+    DevBuf ckpt, resume_t, phase_prof, prio_key;
     // combined controller (stmpc_rollout_step_device / stmpc_combined_decide_device): rollout bookkeeping and probe / controller outputs
     DevBuf cc_live, cc_hist_len, cc_crash_pred, cc_have_test, cc_sel, cc_rollout_s, cc_test_ego, cc_test_ox, cc_test_ov, cc_probe_ego, cc_probe_ox, cc_probe_ov,
         cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err;
@@ -108,6 +108,7 @@ struct stmpc_ctx {
     bool last_has_hbm = true;
     // STMPC_OVERLAP=0/1: start the second LDS tier on its own stream while the first is still running (see k_solve)
     bool resume = true;            // STMPC_RESUME=0/1: the wider window continues a checkpointed exact pass instead of starting over
+    bool heavy_first = false;      // STMPC_HEAVY_FIRST=1: split tasks are handed out slow starters first (measured: 6.76-6.82 vs 6.81-6.82 ms at N=4096, 13.0 vs 12.2 ms at N=8192 -- long searches side by side slow each other down; off)
     int gsh_max = 4;               // STMPC_GSH=0..4: lanes per source of sparse layers, log2 (0 = one lane per source)
     bool split = true;             // STMPC_SPLIT=0/1: bounding and exact pass of an episode are separate tasks of the first launch (-4 % at N=4096)
     int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
@@ -202,6 +203,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
     if (const char *w = getenv("STMPC_BAND_CAP")) { int v = atoi(w); if (v >= 0) c->band_cap = v; }
     if (const char *w = getenv("STMPC_SPLIT")) c->split = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_HEAVY_FIRST")) c->heavy_first = atoi(w) != 0;
     if (const char *w = getenv("STMPC_GSH")) { int v = atoi(w); if (v >= 0 && v <= 4) c->gsh_max = v; }
     if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
@@ -229,7 +231,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
-                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
+                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
                      &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
                      &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
                      &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
@@ -320,9 +322,9 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key);
 }
 
 }  // namespace
@@ -406,17 +408,22 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
     // episode (N x H x W0 x 2 B) instead of per resident workgroup
     const size_t bp0_per_episode = (size_t)N * H * tierW[0] * sizeof(u16);
-    const bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
-                        bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
+    bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
+                  bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
+    const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
+    for (int k = 0; k < nt; ++k) if (tierGrid[k] > N) tierGrid[k] = N;
+    if (resume) {
+        // per-episode back-pointers + checkpoints: if the device cannot spare them (a process shared with torch / RCCL), fall
+        // back to per-workgroup storage -- overflowing episodes then restart in the wider window instead of continuing
+        if (c->bp_tier[0].ensure(bp0_per_episode) || c->ckpt.ensure((size_t)N * ckpt_stride) || c->resume_t.ensure((size_t)N * sizeof(int))) {
+            (void)hipGetLastError();
+            c->bp_tier[0].release(); c->ckpt.release();
+            resume = false;
+        }
+    }
     for (int k = 0; k < nt; ++k) {
-        if (tierGrid[k] > N) tierGrid[k] = N;
         const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * sizeof(u16);
         if ((rc = c->bp_tier[k].ensure(need))) return rc;
-    }
-    const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
-    if (resume) {
-        if ((rc = c->ckpt.ensure((size_t)N * ckpt_stride))) return rc;
-        if ((rc = c->resume_t.ensure((size_t)N * sizeof(int)))) return rc;
     }
     int *resume_t = resume ? c->resume_t.as<int>() : nullptr;
     if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8)))) return rc;
@@ -439,10 +446,13 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     int *queue1 = overlap ? c->lists.as<int>() + (size_t)N : nullptr;
     const bool split = prune_on && !c->two_phase && c->split && N >= 2 * tierGrid[0];
     unsigned *proxy0 = split ? c->proxy.as<unsigned>() : nullptr;
+    const bool heavy_first = split && c->heavy_first;
+    if (heavy_first && (rc = c->prio_key.ensure((size_t)N))) return rc;
+    unsigned char *prio_key = heavy_first ? c->prio_key.as<unsigned char>() : nullptr;
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -494,7 +504,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.prev_grid = side ? tierGrid[0] : 0;
         a.wait_ticks = side ? 20000000ull : 0ull;             // 0.2 s of the 100 MHz clock
         a.phase = phase;
-        a.order = (phase == 2 && k == 0) ? c->order.as<int>() : nullptr;
+        a.order = ((phase == 2 || heavy_first) && k == 0) ? c->order.as<int>() : nullptr;
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
         a.bp0 = (resume && k >= 1) ? c->bp_tier[0].as<u16>() : nullptr;
@@ -533,6 +543,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         return STMPC_OK;
     };
 
+    if (heavy_first) hipLaunchKernelGGL(k_order8, dim3(1), dim3(1024), 0, st, N, (const unsigned char *)prio_key, c->order.as<int>());
     if (two_phase) {                                           // bound every episode, order them heaviest-first
         if ((rc = launch_tier(0, 1, false))) return rc;
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, N, (const unsigned *)c->proxy.as<unsigned>(), c->order.as<int>());
@@ -745,9 +756,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());
