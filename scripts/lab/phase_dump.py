@@ -4,7 +4,9 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 import rl_mpc_lanemerging_amd as pkg
 from rl_mpc_lanemerging_amd import _capi, st, synth
-pkg.apply_overrides(pkg.REFERENCE_DEFAULT); pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+if os.environ.get("PHASE_WORKLOAD", "h40a21") == "h40a21":
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
 p = _capi.Params.from_settings(pkg.Settings)
 out = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ego, k, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=1000)

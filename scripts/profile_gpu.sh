@@ -13,6 +13,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS 
   rocprofv3 --pmc $pass -f csv -d $O/pmc_$n -o p -- $CMD > $O/pmc_$n.log 2>&1
 done
 cd $R
-if [ -f variants/libstmpc_phase.so ]; then STMPC_LIB=$R/variants/libstmpc_phase.so python scripts/lab/phase_dump.py $O/phase.txt > $O/phase_report.txt 2>&1; fi
+WL=h40a21; case "$*" in *default*|*control*) WL=default;; esac
+if [ -f variants/libstmpc_phase.so ]; then PHASE_WORKLOAD=$WL STMPC_LIB=$R/variants/libstmpc_phase.so python scripts/lab/phase_dump.py $O/phase.txt > $O/phase_report.txt 2>&1; fi
 python bench.py --steps 10 --warmup 2 --no-cpu-baseline $* > $O/bench_line.json 2>/dev/null
 find $O -name "*.csv" | head -30
