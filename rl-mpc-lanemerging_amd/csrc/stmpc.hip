@@ -93,6 +93,7 @@ struct stmpc_ctx {
     int n_lds_tiers = 0;          // 0 = automatic: {2048, smallest window covering every cell (<= 8192)}
     int pen_cells[STMPC_MAX_TIERS] = {0, 0, 0, 0, 0, 0};   // STMPC_PEN_CELLS="a,b,c": penalty-buffer cells per LDS tier (0 = min(W, 4096))
     int max_waves_per_cu = 16;
+    int lds_headroom = 1024;       // STMPC_LDS_HEADROOM: bytes added to a workgroup's dynamic LDS when counting workgroups per CU
     int waves_override = 0;       // STMPC_NW=n or "a,b,c": waves per workgroup (episode), all tiers or per LDS tier
     int waves_tier[STMPC_MAX_TIERS] = {0, 0, 0, 0, 0, 0};
     bool tiers_from_env = false;
@@ -171,6 +172,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
         c->tiers_from_env = n > 0;
     }
     if (const char *w = getenv("STMPC_WAVES_PER_CU")) { int v = atoi(w); if (v >= 1 && v <= 32) c->max_waves_per_cu = v; }
+    if (const char *w = getenv("STMPC_LDS_HEADROOM")) { int v = atoi(w); if (v >= 600 && v <= 8192) c->lds_headroom = v; }
     if (const char *w = getenv("STMPC_PEN_CELLS")) {
         int n = 0; const char *q = w;
         while (*q && n < STMPC_MAX_TIERS) {
@@ -390,7 +392,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         if (lds + 2048 > (size_t)c->lds_per_block) break;
         tierW[nt] = W; tierPW[nt] = PW; tierLds[nt] = true; tierLdsBytes[nt] = lds;
         tierNW[nt] = nw;
-        int per_cu = (int)((size_t)(c->lds_per_block) / (lds + 1024));
+        int per_cu = (int)((size_t)(c->lds_per_block) / (lds + c->lds_headroom));      // (+ the kernel's static LDS and allocation granularity)
         int by_waves = c->max_waves_per_cu / tierNW[nt];
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;

@@ -1221,9 +1221,13 @@ __host__ __device__ inline size_t stmpc_chunk_ints(int W) { return (size_t)(W / 
 // LDS bytes of the staged vehicle table: H*KT*(2 doubles + 2 ints) + H ints (8-byte aligned)
 __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_t)H * KT * 24 + (((size_t)H * 4 + 7) & ~(size_t)7); }
 
+// minimum resident waves per SIMD the register allocation is made for (4 = 128 VGPRs; A/B builds override it)
+#ifndef STMPC_MIN_WAVES
+#define STMPC_MIN_WAVES 4
+#endif
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0>
-__global__ void __launch_bounds__(512, (FANMAX <= 12 ? 4 : 2)) k_solve(SolveArgs a) {
+__global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;

@@ -472,6 +472,33 @@ def test_band_cap_never_changes_results(cap, restore_settings, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("gsh,heavy_first", [("0", "0"), ("1", "0"), ("3", "1"), ("4", "1")])
+def test_lane_mapping_and_task_order_never_change_results(gsh, heavy_first, restore_settings, monkeypatch):
+    """Lanes per source of sparse layers (STMPC_GSH: 1, 2, 8 or 16 lanes) and the static task order (STMPC_HEAVY_FIRST) only
+    change who evaluates a candidate and when: every golden file and a 2300-episode wide-fan batch give the same bits."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    monkeypatch.setenv("STMPC_GSH", gsh)
+    monkeypatch.setenv("STMPC_HEAVY_FIRST", heavy_first)
+    ctx = _capi.Context(0)
+    for fname in STATE_FILES:
+        g = load_golden(fname)
+        p, op = settings_from_golden(g)
+        res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
+        _check(res, g, g["t_values"].size)
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    ego, kc, ox, ov = synth.generate_states(2300, k=6, kmax=8, seed=77)
+    res = st.solve_arrays(ego, kc, ox, ov, p, ctx)
+    sel = np.arange(0, 2300, 23)
+    ref = orc.solve_batch(orc.OrcParams.from_dict(p.as_dict()), ego[sel], kc[sel], ox[sel], ov[sel], solver="layered", nthreads=16)
+    for key in ("path_idx", "best_t", "cost", "crash"):
+        assert np.array_equal(res[key][sel], ref[key]), key
+    ctx.close()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("STMPC_FUZZ_BIG_SEEDS", "4")))))
 def test_random_parameter_sets_large_batches(seed, restore_settings):
     """Random wide-fan parameter sets at batch sizes where task splitting, the side launch and checkpoint/resume are all
