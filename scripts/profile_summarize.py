@@ -7,7 +7,7 @@ from collections import defaultdict
 tag, rdir, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs(rdir, exist_ok=True)
-lines = ["# rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline` (%s), scripts/profile_gpu.sh" % workload]
+lines = ["# rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --pipelined 0` (%s), scripts/profile_gpu.sh" % workload]
 steps = 13      # 2 warm-up + 10 timed + 1 statistics step
 # kernel trace
 ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
