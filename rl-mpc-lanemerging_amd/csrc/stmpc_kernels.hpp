@@ -781,10 +781,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // still fills the workgroup's lanes: the candidate loop runs ceil(fan / G) slots instead of fan.  All lanes of a
         // group load the same source (LDS broadcast) and derive the same range; which lane evaluates a candidate
         // does not matter to the staged minimum below.
-        int gsh = 0;
-        if (relax) { while (gsh < a.gsh_max && (nlist << (gsh + 1)) <= per) ++gsh; }
-        const int sub = tid & ((1 << gsh) - 1);
         for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
+            // (chosen per round: the short last round of a wide layer is spread as well)
+            int gsh = 0;
+            if (relax) { while (gsh < a.gsh_max && ((nlist - r0) << (gsh + 1)) <= per) ++gsh; }
+            const int sub = tid & ((1 << gsh) - 1);
             rstep = per >> gsh;
             const int srcidx = r0 + (tid >> gsh);
             const bool inlist = srcidx < nlist;
