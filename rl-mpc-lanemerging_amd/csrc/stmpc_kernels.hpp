@@ -847,8 +847,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             if (!(room >= 0.0)) { if (hi > lo) cut_l = true; lo = 0; hi = 0; }
                             else {
                                 const double rad = sqrt(room * nk.invK);
+#ifdef STMPC_FILTER_MARGIN2
                                 const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
                                 const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
+#else
+                                const double fl = ceil((smin_ - rad - start_s) * r_delta - 0.01);
+                                const double fh = floor((smin_ + rad - start_s) * r_delta + 0.01) + 1.0;
+#endif
                                 const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
                                 const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
                                 if (nlo_ > lo || nhi_ < hi) cut_l = true;
