@@ -833,8 +833,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         // Candidates that cannot stay within the bound are not evaluated.  Without the gap penalty (>= 0)
                         // the edge cost is a quadratic in the candidate position s_n (st_cy.pyx:46-50):
                         //   k_v (s_n - c_v)^2 + k_a (s_n - c_a)^2 + k_j (s_n - c_j)^2  <=  U - C
-                        // holds on an interval around its minimiser.  This is a conservative filter (inflated slack, one
-                        // cell of margin on each side, where the quadratic already exceeds the slack by K*delta^2), so
+                        // holds on an interval around its minimiser.  This is a conservative filter (slack inflated by 1e-9, relative
+                        // and absolute, against the rounding of the evaluated cost, which is below 1e-12 relative), so
                         // every candidate it drops has total cost > U; whatever it keeps is evaluated exactly as before.
                         if (nk.ok && ubits < INF_BITS && hi > lo) {
                             const double slack = (__longlong_as_double((long long)ubits) - C) * (1.0 + 1e-9) + 1e-9;
@@ -847,13 +847,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             if (!(room >= 0.0)) { if (hi > lo) cut_l = true; lo = 0; hi = 0; }
                             else {
                                 const double rad = sqrt(room * nk.invK);
-#ifdef STMPC_FILTER_MARGIN2
-                                const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
-                                const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
-#else
+                                // cells outside [smin_ - rad, smin_ + rad] cost more than the inflated slack; 0.01 cell covers the rounding
+                                // of the lattice coordinates and of this interval (both below 1e-9 cell)
                                 const double fl = ceil((smin_ - rad - start_s) * r_delta - 0.01);
                                 const double fh = floor((smin_ + rad - start_s) * r_delta + 0.01) + 1.0;
-#endif
                                 const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
                                 const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
                                 if (nlo_ > lo || nhi_ < hi) cut_l = true;
@@ -868,9 +865,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         if (nk.ok && hi > lo) {
                             const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
                             const double smin_ = (nk.kv * c_v + nk.ka * c_a + nk.kj * c_j) * nk.invK;
-                            const double rad = sqrt(1.25 * bandt * nk.invK);
-                            const double fl = floor((smin_ - rad - start_s) * r_delta) - 1.0;
-                            const double fh = ceil((smin_ + rad - start_s) * r_delta) + 2.0;
+                            // (no spare cells beyond the interval: the band is a heuristic, and every candidate costs the same ~60 instructions)
+                            const double rad = sqrt(bandt * nk.invK);
+                            const double fl = ceil((smin_ - rad - start_s) * r_delta);
+                            const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
                             const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
                             const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
                             // never drop everything: a source whose whole window lies off the minimiser keeps its nearest end
