@@ -586,7 +586,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         if (tid == 0) sh.flags = fl;
     } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
     M::barrier();
-    out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false;
+    out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false; out.nodes = 0; out.maxspan = 0;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
     double bandt = band;           // PASS_BOUND: the band in force, steered towards a.band_cap expanded nodes per layer
     int total_nodes = 0;
