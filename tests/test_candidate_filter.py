@@ -1,0 +1,113 @@
+"""The exact pass's candidate filter (stmpc_kernels.hpp, dp_pass, "Candidates that cannot stay within the bound"): restated
+in numpy with the kernel's operation order and checked against brute force -- every candidate the interval drops must cost
+more than the bound in the reference's own arithmetic (st_cy.pyx:46-50 edge cost, st_cy.pyx:388 total), including
+candidates whose total equals the bound to the last bit."""
+import numpy as np
+import pytest
+
+
+def _setup(name):
+    import rl_mpc_lanemerging_amd as pkg
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    if name == "h40a21":
+        pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    S = pkg.Settings
+    return dict(dt=float(S.T_DISCRETIZATION), delta=float(S.S_DISCRETIZATION), v_w=float(S.V_WEIGHT), a_w=float(S.A_WEIGHT),
+                j_w=float(S.J_WEIGHT), v_des=float(S.DESIRED_SPEED))
+
+
+def _sval(start, delta, n):
+    return start + n.astype(np.float64) * delta            # numpy arange element (st.py lattice), as the kernel's sval()
+
+
+def _totals(q, start, i, pr, pp, C, n):
+    """C + edge cost of candidate cells n (2-D: trial x candidate), reference operation order."""
+    dt = q["dt"]; dt2 = dt * dt; dt3 = dt2 * dt
+    sv = _sval(start, q["delta"], i)[:, None]; p1 = _sval(start, q["delta"], pr)[:, None]; p2 = _sval(start, q["delta"], pp)[:, None]
+    sn = start[:, None] + n.astype(np.float64) * q["delta"]
+    v = (sn - sv) / dt
+    aa = (sn - 2 * sv + p1) / dt2
+    jj = (sn - 3 * sv + 3 * p1 - p2) / dt3
+    dv = v - q["v_des"]
+    ec = q["v_w"] * (dv * dv) + q["a_w"] * (aa * aa) + q["j_w"] * (jj * jj)
+    return C[:, None] + ec
+
+
+def _interval(q, start, i, pr, pp, C, U):
+    """[nlo, nhi) of the kernel's filter (nhi <= nlo: everything dropped); the kernel then intersects it with the source's range."""
+    dt = q["dt"]; dt2 = dt * dt; dt3 = dt2 * dt
+    kv = q["v_w"] / dt2; ka = q["a_w"] / (dt2 * dt2); kj = q["j_w"] / (dt3 * dt3)
+    invK = 1.0 / (kv + ka + kj)
+    r_delta = 1.0 / q["delta"]
+    sv = _sval(start, q["delta"], i); p1 = _sval(start, q["delta"], pr); p2 = _sval(start, q["delta"], pp)
+    slack = (U - C) * (1.0 + 1e-9) + 1e-9
+    c_v = sv + q["v_des"] * dt; c_a = 2.0 * sv - p1; c_j = 3.0 * sv - 3.0 * p1 + p2
+    num = kv * c_v + ka * c_a + kj * c_j
+    smin = num * invK
+    emin = kv * (c_v - smin) * (c_v - smin) + ka * (c_a - smin) * (c_a - smin) + kj * (c_j - smin) * (c_j - smin)
+    room = slack - emin
+    ok = room >= 0.0
+    rad = np.sqrt(np.where(ok, room, 0.0) * invK)
+    fl = np.ceil((smin - rad - start) * r_delta - 0.01)
+    fh = np.floor((smin + rad - start) * r_delta + 0.01) + 1.0
+    nlo = np.where(ok, fl, 0.0).astype(np.int64); nhi = np.where(ok, fh, 0.0).astype(np.int64)
+    return nlo, nhi
+
+
+def _trials(q, rng, m):
+    start = rng.uniform(-60.0, 400.0, m)
+    i = rng.integers(400, 7000, m)
+    r1 = rng.integers(0, int(30.0 * q["dt"] / q["delta"]) + 1, m)          # previous step: 0 .. v_max
+    r2 = np.clip(r1 + rng.integers(-40, 41, m), 0, None)                  # the one before: a plausible acceleration
+    pr = i - r1; pp = pr - r2
+    C = rng.uniform(0.0, 6000.0, m) * rng.choice([1.0, 1e-3], m)
+    return start, i, pr, pp, C
+
+
+@pytest.mark.parametrize("name", ["h40a21", "default"])
+def test_filter_never_drops_a_candidate_within_the_bound(name):
+    q = _setup(name)
+    rng = np.random.default_rng(7)
+    m = 40000
+    start, i, pr, pp, C = _trials(q, rng, m)
+    span = np.arange(-60, 400)                                            # candidates i-60 .. i+399 (the dynamic range is within i .. i+~190)
+    n = i[:, None] + span[None, :]
+    tot = _totals(q, start, i, pr, pp, C, n)
+    # bounds: random slack, the exact total of a random candidate, and its neighbours in floating point
+    pick = rng.integers(0, span.size, m)
+    t_pick = tot[np.arange(m), pick]
+    kinds = rng.integers(0, 4, m)
+    U = np.where(kinds == 0, C + rng.uniform(0.0, 800.0, m),
+        np.where(kinds == 1, t_pick, np.where(kinds == 2, np.nextafter(t_pick, np.inf), np.nextafter(t_pick, -np.inf))))
+    nlo, nhi = _interval(q, start, i, pr, pp, C, U)
+    within = tot <= U[:, None]
+    kept = (n >= nlo[:, None]) & (n < nhi[:, None])
+    bad = within & ~kept
+    assert not bad.any(), "dropped a candidate with total <= bound: trial %d" % int(np.argwhere(bad)[0][0])
+    # and it is a filter worth having: away from the equality cases it keeps at most one cell beyond the true interval on either side
+    true_n = within.sum(1); kept_n = kept.sum(1)
+    sel = (kinds == 0) & (true_n > 0)
+    assert sel.sum() > 1000 and (kept_n[sel] - true_n[sel]).max() <= 2
+    assert (kinds == 1).sum() > 1000 and within[kinds == 1].any(1).all()     # the equality cases really contain their candidate
+
+
+def test_filter_holds_at_large_coordinates_and_tiny_slack():
+    """Far lattice (s ~ 1e4 m) and slacks down to 1e-7: the regime where rounding of the coordinates is largest relative to the interval."""
+    q = _setup("h40a21")
+    rng = np.random.default_rng(11)
+    m = 20000
+    start = rng.uniform(5000.0, 20000.0, m)
+    i = rng.integers(400, 60000, m)
+    r1 = rng.integers(0, 181, m); r2 = np.clip(r1 + rng.integers(-5, 6, m), 0, None)
+    pr = i - r1; pp = pr - r2
+    C = rng.uniform(0.0, 100.0, m)
+    span = np.arange(-20, 260)
+    n = i[:, None] + span[None, :]
+    tot = _totals(q, start, i, pr, pp, C, n)
+    best = tot.min(1)
+    U = best + 10.0 ** rng.uniform(-7, 1, m) * rng.choice([0.0, 1.0], m, p=[0.1, 0.9])     # 10 %: the bound IS the cheapest candidate's total
+    nlo, nhi = _interval(q, start, i, pr, pp, C, U)
+    within = tot <= U[:, None]
+    kept = (n >= nlo[:, None]) & (n < nhi[:, None])
+    assert not (within & ~kept).any()
+    assert within.any(1).all()
