@@ -520,11 +520,20 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS>), grid, block, lds, lst, a);           \
         } while (0)
+        // (the first window's four-wave workgroups: list segments searched with 3 compares instead of 7)
+#define STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, RS)                                                               \
+        do {                                                                                                  \
+            if (lds > 48 * 1024)                                                                              \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG, RS, 4>,           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 4>), grid, block, lds, lst, a);        \
+        } while (0)
         // checkpointing variants only where they are used: the first window saves, the second continues
 #define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
             if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
-                if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                                  \
+                if (resume && k == 0 && tierNW[0] <= 4) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
+                else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
                 else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                   \
             } else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                     \
@@ -542,6 +551,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 #undef STMPC_LAUNCH
 #undef STMPC_LAUNCH_S
 #undef STMPC_LAUNCH_R
+#undef STMPC_LAUNCH_R4
         return STMPC_OK;
     };
 

@@ -545,7 +545,8 @@ __device__ __attribute__((noinline)) void ckpt_load(const unsigned char *ck, int
 }
 
 // RES: 0 no checkpointing, 1 this tier saves a layer it cannot build (first window), 2 this tier may continue from one
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN, int RES = 0>
+// NWX: the most waves per workgroup the instantiation serves (list segments are searched with NWX - 1 compares)
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
                        u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
                        u64 ubits, double band, bool hardsoft, PassOut &out, const int t_start = 0) {
@@ -731,19 +732,19 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
         M::barrier();        // S1
         STMPC_PH(2);                    // 2: scan + S1
-        int segbase[STMPC_MAXWAVES + 1];
+        int segbase[NWX + 1];
         segbase[0] = 0;
 #pragma unroll
-        for (int w = 0; w < STMPC_MAXWAVES; ++w)      // wave-uniform: keep the boundaries in scalar registers
+        for (int w = 0; w < NWX; ++w)                 // wave-uniform: keep the boundaries in scalar registers
             segbase[w + 1] = segbase[w] + __builtin_amdgcn_readfirstlane(w < NW ? sh.cnt[w] : 0);
-        const int nlist = segbase[STMPC_MAXWAVES];
+        const int nlist = segbase[NWX];
         auto list_at = [&](int g) -> int {                   // g-th selected cell of the layer, descending
             int w = 0;
 #pragma unroll
-            for (int k = 1; k < STMPC_MAXWAVES; ++k) w += (g >= segbase[k]) ? 1 : 0;
+            for (int k = 1; k < NWX; ++k) w += (g >= segbase[k]) ? 1 : 0;
             int basew = segbase[0];
 #pragma unroll
-            for (int k = 1; k < STMPC_MAXWAVES; ++k) basew = (w == k) ? segbase[k] : basew;
+            for (int k = 1; k < NWX; ++k) basew = (w == k) ? segbase[k] : basew;
             return (int)M::ld16(&list[w * cpw * 64 + (g - basew)]);
         };
         total_nodes += nlist;
@@ -1039,7 +1040,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 }
 
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
                              double *pen, u16 *list, int *chunk_cnt, double *ltab_e, int *ltab_w, int *ltab_n, const int phase) {
     const DevP &p = a.p;
@@ -1106,7 +1107,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             // (one call site in a loop: a second inlined copy of the pass would add a third to the kernel's code size)
             int rc = 0, bn = 0;
             for (int att = 0; att < 2; ++att) {
-                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
+                rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN, 0, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
                                                                                    att == 0 ? a.band : a.band * a.band2_mult, att == 0, out);
                 bn += out.nodes;
                 if (rc != 0) break;
@@ -1131,7 +1132,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     if constexpr (RES == 2) { if (have_bound) t_res = a.resume_t[e]; }
     for (int attempt = 0;; ++attempt) {
         if (attempt > 0) t_res = 0;     // a relaxed bound invalidates the checkpoint: start over
-        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN, RES>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out, t_res);
+        int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN, RES, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out, t_res);
         if (rc != 0) {
             if constexpr (!GRID) {
                 if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;    // 0 is reserved for "unknown"
@@ -1230,7 +1231,7 @@ __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_
 #define STMPC_MIN_WAVES 4
 #endif
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
-template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0>
+template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
@@ -1338,7 +1339,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
             if (e < 0) break;
             const int task_phase = (a.tier == 0) ? sh.rc : a.phase;
             if (task_phase == 3) continue;
-            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN, RES>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);
+            int rc = solve_episode<USE_LDS, false, FASTDIV, KT, FANMAX, S1GEN, RES, NWX>(a, e, blockIdx.x, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, task_phase);
             if (rc != 0 && tid == 0) {
                 if (!a.last_tier) {
                     atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
