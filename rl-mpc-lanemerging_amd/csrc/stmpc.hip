@@ -528,6 +528,11 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 4>), grid, block, lds, lst, a);        \
         } while (0)
+#define STMPC_LAUNCH_R0(L, FD, KT_, FM, SG)                                                                   \
+        do {                                                                                                  \
+            if constexpr (L) { if (tierNW[k] <= 4) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 0); else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0); } \
+            else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                       \
+        } while (0)
         // checkpointing variants only where they are used: the first window saves, the second continues
 #define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
@@ -535,8 +540,8 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                 if (resume && k == 0 && tierNW[0] <= 4) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
                 else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
-                else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                   \
-            } else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                     \
+                else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                     \
+            } else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                       \
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
@@ -552,6 +557,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 #undef STMPC_LAUNCH_S
 #undef STMPC_LAUNCH_R
 #undef STMPC_LAUNCH_R4
+#undef STMPC_LAUNCH_R0
         return STMPC_OK;
     };
 
