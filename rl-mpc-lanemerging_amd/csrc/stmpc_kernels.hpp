@@ -555,8 +555,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int NW = blockDim.x >> 6;
-    const int per = blockDim.x;
+    const int NW = (NWX == 4) ? 4 : (int)(blockDim.x >> 6);          // (NWX == 4 is only launched with exactly four waves)
+    const int per = NW * 64;
     const int W = a.W, WM = a.W - 1;
     const int PW = a.PW, PWM = a.PW - 1;
     const int H = p.H, S = ep.S, e = ep.e;
