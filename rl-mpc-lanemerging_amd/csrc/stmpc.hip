@@ -512,6 +512,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.bp0 = (resume && k >= 1) ? c->bp_tier[0].as<u16>() : nullptr;
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
+        const bool std_shape = tierNW[k] == 4 && tierW[k] == 2048 && tierPW[k] == 1024;      // the kernels compiled with these as constants
         const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
 #define STMPC_LAUNCH_R(L, FD, KT_, FM, SG, RS)                                                                \
         do {                                                                                                  \
@@ -530,14 +531,14 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         } while (0)
 #define STMPC_LAUNCH_R0(L, FD, KT_, FM, SG)                                                                   \
         do {                                                                                                  \
-            if constexpr (L) { if (tierNW[k] == 4) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 0); else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0); } \
+            if constexpr (L) { if (std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 0); else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0); } \
             else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0);                                                       \
         } while (0)
         // checkpointing variants only where they are used: the first window saves, the second continues
 #define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
             if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
-                if (resume && k == 0 && tierNW[0] == 4) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
+                if (resume && k == 0 && std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
                 else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
                 else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                     \

@@ -557,8 +557,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const int wave = tid >> 6;
     const int NW = (NWX == 4) ? 4 : (int)(blockDim.x >> 6);          // (NWX == 4 is only launched with exactly four waves)
     const int per = NW * 64;
-    const int W = a.W, WM = a.W - 1;
-    const int PW = a.PW, PWM = a.PW - 1;
+    // (NWX == 4: the standard first window -- 2048 cells, 1024 penalty entries -- with its sizes as immediates)
+    const int W = (NWX == 4) ? 2048 : a.W, WM = W - 1;
+    const int PW = (NWX == 4) ? 1024 : a.PW, PWM = PW - 1;
     const int H = p.H, S = ep.S, e = ep.e;
     const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
@@ -1046,7 +1047,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     const DevP &p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int W = a.W, WM = a.W - 1;
+    const int W = (NWX == 4) ? 2048 : a.W, WM = W - 1;
     const int H = p.H;
     Ep ep;
     if constexpr (GRID) {
@@ -1236,7 +1237,8 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;
-    const int W = a.W;
+    const int W = (NWX == 4) ? 2048 : a.W;
+    const int PWc = (NWX == 4) ? 1024 : a.PW;
     unsigned char *base;
     int *chunk_cnt;
     // dynamic LDS: [vehicle table][chunk counters][cell arrays (LDS tiers only)]
@@ -1248,10 +1250,10 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
     chunk_cnt = (int *)after_tab;
     unsigned char *cells = after_tab + ((stmpc_chunk_ints(W) * sizeof(int) + 15) & ~(size_t)15);
     if constexpr (USE_LDS) base = cells;
-    else base = a.gscratch + (size_t)blockIdx.x * ((size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)a.PW * 8);
+    else base = a.gscratch + (size_t)blockIdx.x * ((size_t)W * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)PWc * 8);
     u64 *cost = (u64 *)base;
     double *pen = (double *)(cost + W);
-    unsigned *hist = (unsigned *)(pen + a.PW);
+    unsigned *hist = (unsigned *)(pen + PWc);
     u16 *list = (u16 *)(hist + W);
 
     if constexpr (GRID) {
