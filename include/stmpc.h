@@ -311,8 +311,15 @@ int stmpc_sim_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_sim
 int stmpc_sim_read(stmpc_ctx *ctx, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4);
 
 /* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
- * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b) HOST pointers. */
+ * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b), 5 the five-operation
+ * quotient a/b of the FASTDIV kernels, 6 their two-operation quotient a/b.  HOST pointers. */
 int stmpc_probe_arith(stmpc_ctx *ctx, int op, const double *a, const double *b, double *out, int n);
+
+/* The check the solver applies to dt, dt^2 and dt^3 (st_cy.pyx:46-50 divides by them once per edge) before it launches the kernels
+ * that form these quotients as fma(x, zh, x*zl): returns 1 if that equals x / d for every double x (quotient in the normal range),
+ * 0 if some x would round differently or the check cannot be completed -- the solver then divides with the ordinary IEEE sequence.
+ * *zl (may be NULL) receives RN(1/d - RN(1/d)).  Host-only, no context. */
+int stmpc_fastdiv2_check(double d, double *zl);
 
 #ifdef __cplusplus
 }

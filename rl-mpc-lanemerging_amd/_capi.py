@@ -86,7 +86,7 @@ EXPORTS = (
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
     "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
-    "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read",
+    "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check",
 )
 
 QP_NMAX = 64        # STMPC_QP_NMAX
@@ -129,6 +129,7 @@ def load():
     lib.stmpc_num_t.argtypes = [pp]
     lib.stmpc_path_mean_abs_jerk.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double]
     lib.stmpc_path_mean_abs_jerk.restype = C.c_double
+    lib.stmpc_fastdiv2_check.argtypes = [C.c_double, C.POINTER(C.c_double)]
     lib.stmpc_solve_batch_device.argtypes = [vp, pp, C.c_int, C.c_int] + [vp] * 9 + [vp]
     lib.stmpc_solve_batch.argtypes = [vp, pp, C.c_int, C.c_int, dp, ip, dp, dp, ip, ip, dp, dp, ip]
     lib.stmpc_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -183,6 +184,13 @@ def num_t(params):
 
 def path_mean_abs_jerk(seq, v0, a0, dt):
     return load().stmpc_path_mean_abs_jerk(_dptr(seq), int(seq.size), float(v0), float(a0), float(dt))
+
+
+def fastdiv2_check(d):
+    """(ok, zl): whether the solver may form x / d as fma(x, RN(1/d), x * zl) -- the check it applies to dt, dt**2, dt**3."""
+    zl = C.c_double(0.0)
+    ok = load().stmpc_fastdiv2_check(float(d), C.byref(zl))
+    return bool(ok), zl.value
 
 
 def backend_info():

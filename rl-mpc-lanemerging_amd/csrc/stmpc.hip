@@ -61,6 +61,60 @@ bool fastdiv_ok(double d) {
     return (d > 1e-100 && d < 1e100) && ((b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull);
 }
 
+// Two-operation division by d (divk in stmpc_kernels.hpp): true, with *zl = RN(1/d - RN(1/d)), if fma(x, zh, x*zl) == x/d for
+// EVERY double x whose quotient neither overflows nor falls into the subnormals.  The sequence can only round wrongly when x/d
+// lies within 2^-52 ulp of a midpoint, i.e. |2^t X - (2M+1) D| < 8 D 2^-52 (four-fold safety) for the significands X of x and D of d
+// (odd part, L bits), t in {L-1, L, L+1}: each residue r has at most a few X in [2^52, 2^53).  All of them, their neighbours, both
+// signs and three binades are run through the real arithmetic here (the CPU's fma and division are IEEE like the GPU's).
+// oracle/analysis/div2_check.py replays the argument exhaustively in 8-10 bit formats.
+bool fastdiv2_ok(double d, double *zl_out) {
+    if (!(d > 1e-100 && d < 1e100)) return false;
+    const double zh = 1.0 / d;
+    const double zl = std::fma(-d, zh, 1.0) / d;
+    *zl_out = zl;
+    int e2;
+    const double m = std::frexp(d, &e2);
+    uint64_t D = (uint64_t)std::ldexp(m, 53);
+    while ((D & 1) == 0) D >>= 1;
+    auto two = [&](double x) { volatile double u1 = x * zl; return std::fma(x, zh, (double)u1); };
+    auto good = [&](double x) { return two(x) == x / d && two(-x) == -x / d; };
+    if (D > 1) {
+        int L = 0; while ((D >> L) != 0) ++L;
+        const long long R = (long long)(((unsigned __int128)D * 8) >> 52) + 1;
+        for (int t = L - 1; t <= L + 1; ++t) {
+            // 2^t mod D, then its inverse (extended Euclid)
+            unsigned __int128 pw = 1; for (int k = 0; k < t; ++k) pw = (pw * 2) % D;
+            long long a0 = (long long)D, a1 = (long long)(uint64_t)pw, x0 = 0, x1 = 1;
+            while (a1 != 0) { const long long q = a0 / a1, a2 = a0 - q * a1, x2 = x0 - q * x1; a0 = a1; a1 = a2; x0 = x1; x1 = x2; }
+            if (a0 != 1) return false;                               // (cannot happen: D is odd)
+            const uint64_t inv = (uint64_t)((x0 % (long long)D + (long long)D) % (long long)D);
+            for (long long r = -R; r <= R; ++r) {
+                if (r == 0) continue;
+                const uint64_t rm = (uint64_t)(((r % (long long)D) + (long long)D) % (long long)D);
+                uint64_t X = (uint64_t)(((unsigned __int128)rm * inv) % D);
+                const uint64_t lo = 1ull << 52, hi = 1ull << 53;
+                if (X < lo) X += ((lo - X + D - 1) / D) * D;
+                int n = 0;
+                for (; X < hi; X += D) {
+                    if (++n > 4096) return false;                    // too many close calls to try: use ordinary division
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const double xb = (double)(X + dx);
+                        if (!good(xb) || !good(std::ldexp(xb, -40)) || !good(std::ldexp(xb, 30))) return false;
+                    }
+                }
+            }
+        }
+    }
+    // (not part of the argument: a smoke test of the arithmetic on ordinary values)
+    uint64_t st_ = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < 4096; ++k) {
+        st_ ^= st_ << 13; st_ ^= st_ >> 7; st_ ^= st_ << 17;
+        const double x = (double)(st_ >> 11) * (1.0 / 9007199254740992.0) * 2.0e4 - 1.0e4;
+        if (two(x) != x / d) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 struct stmpc_ctx {
@@ -98,6 +152,7 @@ struct stmpc_ctx {
     int waves_tier[STMPC_MAX_TIERS] = {0, 0, 0, 0, 0, 0};
     bool tiers_from_env = false;
     bool allow_fastdiv = true;
+    double fd2_dt = 0, fd2_dt2 = 0, fd2_dt3 = 0, fd2_zl[3] = {0, 0, 0}; bool fd2_ok = false;      // fastdiv2_ok results for the current dt
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
     int band_cap = 300;            // STMPC_BAND_CAP: nodes per layer the pre-pass steers its band towards (0 = fixed band)
@@ -350,7 +405,13 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const int S_nom = stmpc_num_s(p, 0.0);
     if (S_nom < 2 || S_nom + 2 > STMPC_S_LIMIT) return fail(STMPC_EINVAL, "number of position cells out of range");
     const int Kalloc = Kmax > 0 ? Kmax : 1;
-    const bool fastdiv = c->allow_fastdiv && fastdiv_ok(dp.dt) && fastdiv_ok(dp.dt2) && fastdiv_ok(dp.dt3);
+    // FASTDIV kernels: Markstein's five-operation quotient for the lattice step (per-episode value), the two-operation one for
+    // dt, dt^2, dt^3 once each of them has passed fastdiv2_ok (cached per context: the check costs a few hundred divisions)
+    if (c->fd2_dt != dp.dt || c->fd2_dt2 != dp.dt2 || c->fd2_dt3 != dp.dt3) {
+        c->fd2_dt = dp.dt; c->fd2_dt2 = dp.dt2; c->fd2_dt3 = dp.dt3;
+        c->fd2_ok = fastdiv2_ok(dp.dt, &c->fd2_zl[0]) && fastdiv2_ok(dp.dt2, &c->fd2_zl[1]) && fastdiv2_ok(dp.dt3, &c->fd2_zl[2]);
+    }
+    const bool fastdiv = c->allow_fastdiv && fastdiv_ok(dp.dt) && fastdiv_ok(dp.dt2) && fastdiv_ok(dp.dt3) && c->fd2_ok;
 
     // scratch
     if ((rc = c->tab_edge.ensure((size_t)N * H * Kalloc * 2 * sizeof(double)))) return rc;
@@ -481,6 +542,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.band_cap = c->band_cap;
     a.force_general = c->force_general ? 1 : 0;
     a.gsh_max = c->gsh_max;
+    a.zl_dt = c->fd2_zl[0]; a.zl_dt2 = c->fd2_zl[1]; a.zl_dt3 = c->fd2_zl[2];
 #ifdef STMPC_PHASE_PROF
     if ((rc = c->phase_prof.ensure(2 * STMPC_NPH * sizeof(unsigned long long)))) return rc;
     HIPCHK(hipMemsetAsync(c->phase_prof.p, 0, 2 * STMPC_NPH * sizeof(unsigned long long), st));
@@ -842,6 +904,13 @@ int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, in
     HIPCHK(hipMemcpy(crashed, c->s_crash.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     if (oa_out && Kmax > 0) HIPCHK(hipMemcpy(oa_out, c->s_pd.p, (size_t)N * Kmax * 8, hipMemcpyDeviceToHost));
     return STMPC_OK;
+}
+
+int stmpc_fastdiv2_check(double d, double *zl) {
+    double z = 0.0;
+    const bool ok = fastdiv2_ok(d, &z);
+    if (zl) *zl = z;
+    return ok ? 1 : 0;
 }
 
 int stmpc_probe_arith(stmpc_ctx *c, int op, const double *a, const double *b, double *out, int n) {

@@ -357,6 +357,17 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
     }
 }
 
+// x / d for one of the launch's CONSTANT divisors (dt, dt^2, dt^3) in two operations: zh = RN(1/d), zl = RN(1/d - zh).
+// fma(x, zh, RN(x*zl)) equals x/d to 2^-105 relative before its rounding, i.e. it is RN(x/d) unless x/d lies within 2^-52 ulp
+// of a midpoint; for a given d only a few dozen significands x can come that close, and the host tries every one of them
+// (fastdiv2_ok in stmpc.hip; the argument and its exhaustive replay in small formats: oracle/analysis/div2_check.py).
+// A divisor that fails the check, or was not checked, never gets here: FASTDIV is then false and x / d is used.
+template <bool FASTDIV>
+__device__ __forceinline__ double divk(double x, double d, double zh, double zl) {
+    if constexpr (FASTDIV) return __builtin_fma(x, zh, x * zl);
+    else return x / d;
+}
+
 #define STMPC_MAX_TIERS 6
 #define STMPC_PROXY_MOVED 0xffffffffu   // split tasks: the bounding task sent the episode to the next tier
 #define STMPC_CNT_CONSUMED 32   // + 2*tier + {0 unbounded, 1 bounded}: entries of the tier's queue handed out
@@ -409,6 +420,7 @@ struct SolveArgs {
     int maxshift;          // upper bound of (target cell - source cell) + rounding slack of the interval bookkeeping
     unsigned long long *phase_prof;   // analysis builds: [2][16] clock totals per pass and phase, else null
     int gsh_max;           // a sparse layer spreads a source over up to 2^gsh_max lanes (dp_pass)
+    double zl_dt, zl_dt2, zl_dt3;   // low words of 1/dt, 1/dt^2, 1/dt^3 (divk); meaningful when the FASTDIV kernels are launched
     int split;             // tier 0 hands out 2N tasks: the bounding pre-passes of all episodes, then their exact passes
     int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
@@ -564,6 +576,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
     const double r_dt = ep.r_dt, r_dt2 = ep.r_dt2, r_dt3 = ep.r_dt3, r_delta = ep.r_delta;
+    const double zl_dt = a.zl_dt, zl_dt2 = a.zl_dt2, zl_dt3 = a.zl_dt3;
     const bool s1_plain = ep.s1_plain;
     auto sval = [&](int n) -> double {
         if constexpr (GRID) return a.s_values[n];
@@ -814,9 +827,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 }
                 if (relax) {
                     // st_cy.pyx:65-75
-                    double prev_v = divc<FASTDIV>(p1 - p2, dt, r_dt);
-                    double v = divc<FASTDIV>(sv - p1, dt, r_dt);
-                    double acc = divc<FASTDIV>(v - prev_v, dt, r_dt);
+                    double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
+                    double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
+                    double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
                     double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
                     double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
                     double min_v = dmax_py(v + min_a * dt, 0.0);
@@ -960,9 +973,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             const int n = cand(cbase + ub + u);
                             const double sn = sval(n);
                             // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
-                            const double v = divc<FASTDIV>(sn - sv, dt, r_dt);
-                            const double aa = divc<FASTDIV>(sn - two_sv + p1, dt2, r_dt2);
-                            const double jj = divc<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3);
+                            const double v = divk<FASTDIV>(sn - sv, dt, r_dt, zl_dt);
+                            const double aa = divk<FASTDIV>(sn - two_sv + p1, dt2, r_dt2, zl_dt2);
+                            const double jj = divk<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3, zl_dt3);
                             const double dv = v - p.v_des;
                             const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn[u];
                             const double tot = C + ec;                       // st_cy.pyx:388
@@ -1430,6 +1443,7 @@ __global__ void k_probe(int op, const double *a, const double *b, double *out, i
         case 2: r = x * y; break;
         case 3: r = x + y; break;
         case 5: r = divc<true>(x, y, 1.0 / y); break;
+        case 6: { const double zh = 1.0 / y; r = divk<true>(x, y, zh, __builtin_fma(-y, zh, 1.0) / y); break; }   // (zl as fastdiv2_ok computes it)
         default: r = __builtin_fma(x, x, y * y); break;
     }
     out[i] = r;

@@ -1,0 +1,108 @@
+"""Two-operation division by dt, dt^2, dt^3 (divk in stmpc_kernels.hpp; host check fastdiv2_ok in stmpc.hip): the argument is
+replayed exhaustively in small floating-point formats, the library's check is compared with an exact-arithmetic prototype
+(oracle/analysis/div2_check.py), and on the GPU the sequence is run on exactly the inputs that come closest to a rounding
+boundary -- for divisors that pass the check and for one that does not."""
+import importlib.util
+import os
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAILING_D = 0.3500034505541218       # found by scanning random divisors with the library's check; see test below
+
+
+def _proto():
+    spec = importlib.util.spec_from_file_location("div2_check", os.path.join(ROOT, "oracle", "analysis", "div2_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _dts():
+    import rl_mpc_lanemerging_amd as pkg
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    dt = float(pkg.Settings.T_DISCRETIZATION)          # 0.30 in every shipped config (configs/*.json)
+    return [dt, dt * dt, dt * dt * dt]
+
+
+@pytest.mark.parametrize("p", [8, 9])
+def test_candidate_argument_holds_exhaustively_in_small_formats(p):
+    """Every (x, d) pair of a p-bit format for which the two-operation quotient rounds wrongly is among the listed candidates,
+    and such pairs exist -- the per-divisor check is not a formality."""
+    bad, missed = _proto().toy_exhaustive(p)
+    assert bad > 0 and missed == 0
+
+
+def test_library_check_agrees_with_exact_arithmetic():
+    from rl_mpc_lanemerging_amd import _capi
+    d2 = _proto()
+    for d in _dts() + [0.2, 0.04, 0.008, 0.05, 0.1, 1.0 / 3.0, 0.25, 3.0, FAILING_D]:
+        ok, zl = _capi.fastdiv2_check(d)
+        assert ok == d2.verify_double(d), d
+        zh = 1.0 / d
+        from fractions import Fraction
+        assert Fraction(zl) == d2.rn(Fraction(1) / Fraction(d) - Fraction(zh), 53), d
+    assert all(_capi.fastdiv2_check(d)[0] for d in _dts())            # the reference's dt: the fast kernels are the ones that run
+    assert not _capi.fastdiv2_check(FAILING_D)[0]
+    # the failing divisor really has an input that rounds differently (exact arithmetic, no hardware involved)
+    from fractions import Fraction
+    import math
+    m, _ = math.frexp(FAILING_D)
+    wrong = [X for X in d2.candidates(int(m * (1 << 53)), 53)
+             if d2.two_op(Fraction(X), Fraction(FAILING_D), 53) != d2.rn(Fraction(X) / Fraction(FAILING_D), 53)]
+    assert wrong
+
+
+def test_about_one_divisor_in_a_hundred_fails_the_check():
+    from rl_mpc_lanemerging_amd import _capi
+    rng = np.random.default_rng(3)
+    n = sum(not _capi.fastdiv2_check(float(d))[0] for d in rng.uniform(0.05, 1.0, 20000))
+    assert 50 < n < 800
+
+
+def _close_calls(d):
+    """Inputs whose quotient by d comes closest to a rounding boundary (+ neighbours, binades, signs) and ordinary ones."""
+    import math
+    d2 = _proto()
+    m, _ = math.frexp(d)
+    c = d2.candidates(int(m * (1 << 53)), 53)
+    xs = []
+    for X in c:
+        for dx in (-1, 0, 1):
+            for sc in (1.0, 2.0 ** -44, 2.0 ** -50, 2.0 ** 20):
+                xs += [float(X + dx) * sc, -float(X + dx) * sc]
+    rng = np.random.default_rng(9)
+    xs += list(rng.uniform(-400.0, 400.0, 200000)) + list(rng.uniform(-1e-3, 1e-3, 20000)) + [0.0]
+    return np.array(xs)
+
+
+@pytest.mark.gpu
+def test_gpu_two_operation_quotient_is_the_ieee_quotient(gpu_ctx):
+    for d in _dts() + [0.2, 0.04, 0.008]:
+        x = _close_calls(d)
+        q = gpu_ctx.probe_arith(6, x, np.full_like(x, d))
+        assert np.array_equal(q, x / d), d
+    # and where the check says no, the GPU's arithmetic shows why (same bits as the exact-arithmetic prototype predicts)
+    x = _close_calls(FAILING_D)
+    q = gpu_ctx.probe_arith(6, x, np.full_like(x, FAILING_D))
+    assert (q != x / FAILING_D).any()
+
+
+@pytest.mark.gpu
+def test_gpu_solver_with_a_dt_that_fails_the_check(gpu_ctx, restore_settings):
+    """T_DISCRETIZATION = a divisor the check rejects: the solver must take the IEEE-division kernels and stay bit-exact."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    H = 24
+    pkg.apply_overrides({"T_DISCRETIZATION": FAILING_D, "FUTURE_T": (H - 1) * FAILING_D + 1e-9, "FUTURE_S": 300.0})
+    p = _capi.Params.from_settings(pkg.Settings)
+    assert not _capi.fastdiv2_check(p.dt)[0]
+    ego, kc, ox, ov = synth.generate_states(600, k=6, kmax=8, seed=31)
+    res = st.solve_arrays(ego, kc, ox, ov, p, gpu_ctx)
+    sel = np.arange(0, 600, 5)
+    ref = orc.solve_batch(orc.OrcParams.from_dict(p.as_dict()), ego[sel], kc[sel], ox[sel], ov[sel], solver="layered", nthreads=16)
+    for key in ("path_idx", "best_t", "cost", "crash"):
+        assert np.array_equal(res[key][sel], ref[key]), key
