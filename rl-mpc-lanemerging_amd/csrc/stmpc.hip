@@ -66,7 +66,7 @@ bool fastdiv_ok(double d) {
 // lies within 2^-52 ulp of a midpoint, i.e. |2^t X - (2M+1) D| < 8 D 2^-52 (four-fold safety) for the significands X of x and D of d
 // (odd part, L bits), t in {L-1, L, L+1}: each residue r has at most a few X in [2^52, 2^53).  All of them, their neighbours, both
 // signs and three binades are run through the real arithmetic here (the CPU's fma and division are IEEE like the GPU's).
-// oracle/analysis/div2_check.py replays the argument exhaustively in 8-10 bit formats.
+// tests/div2_check.py replays the argument exhaustively in 8-10 bit formats.
 bool fastdiv2_ok(double d, double *zl_out) {
     if (!(d > 1e-100 && d < 1e100)) return false;
     const double zh = 1.0 / d;

@@ -360,7 +360,7 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
 // x / d for one of the launch's CONSTANT divisors (dt, dt^2, dt^3) in two operations: zh = RN(1/d), zl = RN(1/d - zh).
 // fma(x, zh, RN(x*zl)) equals x/d to 2^-105 relative before its rounding, i.e. it is RN(x/d) unless x/d lies within 2^-52 ulp
 // of a midpoint; for a given d only a few dozen significands x can come that close, and the host tries every one of them
-// (fastdiv2_ok in stmpc.hip; the argument and its exhaustive replay in small formats: oracle/analysis/div2_check.py).
+// (fastdiv2_ok in stmpc.hip; the argument and its exhaustive replay in small formats: tests/div2_check.py).
 // A divisor that fails the check, or was not checked, never gets here: FASTDIV is then false and x / d is used.
 template <bool FASTDIV>
 __device__ __forceinline__ double divk(double x, double d, double zh, double zl) {

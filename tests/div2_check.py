@@ -5,7 +5,7 @@ differs from x/d by at most 2^-105 relative before its final rounding, so q = RN
 midpoint of two adjacent floats.  For p-bit mantissas X (of x) and D (odd part of d's mantissa, L bits) that means
 |2^t X - (2M+1) D| < 2 D 2^-(p-1) for t in {L-1, L}: a handful of residues r, each with at most a few X.  candidates() lists
 them; verify() runs the actual two-operation sequence on every one of them (and their neighbours).  This file is the
-prototype and the self-test of that argument: toy_exhaustive() replays it in a 10..12-bit floating-point format where ALL
+prototype and the self-test of that argument (test infrastructure: only tests/ import it): toy_exhaustive() replays it in a 10..12-bit floating-point format where ALL
 (X, D) pairs can be tried, and checks that every failing pair is among the candidates.  The product's C++ twin is
 fastdiv2_ok() in stmpc.hip.  (Brisebarre & Muller, "Correctly rounded multiplication by arbitrary precision constants",
 IEEE TC 2008, give the general theory; only the elementary bound above is used here.)"""

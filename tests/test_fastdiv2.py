@@ -1,6 +1,6 @@
 """Two-operation division by dt, dt^2, dt^3 (divk in stmpc_kernels.hpp; host check fastdiv2_ok in stmpc.hip): the argument is
 replayed exhaustively in small floating-point formats, the library's check is compared with an exact-arithmetic prototype
-(oracle/analysis/div2_check.py), and on the GPU the sequence is run on exactly the inputs that come closest to a rounding
+(tests/div2_check.py), and on the GPU the sequence is run on exactly the inputs that come closest to a rounding
 boundary -- for divisors that pass the check and for one that does not."""
 import importlib.util
 import os
@@ -12,7 +12,7 @@ FAILING_D = 0.3500034505541218       # found by scanning random divisors with th
 
 
 def _proto():
-    spec = importlib.util.spec_from_file_location("div2_check", os.path.join(ROOT, "oracle", "analysis", "div2_check.py"))
+    spec = importlib.util.spec_from_file_location("div2_check", os.path.join(ROOT, "tests", "div2_check.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
