@@ -47,7 +47,7 @@ def _interval(q, start, i, pr, pp, C, U):
     emin = kv * (c_v - smin) * (c_v - smin) + ka * (c_a - smin) * (c_a - smin) + kj * (c_j - smin) * (c_j - smin)
     room = slack - emin
     ok = room >= 0.0
-    rad = np.sqrt(np.where(ok, room, 0.0) * invK)
+    rad = (np.sqrt((np.where(ok, room, 0.0) * invK).astype(np.float32)) * np.float32(1.000001)).astype(np.float64)      # as the kernel: float sqrt, nudged up
     fl = np.ceil((smin - rad - start) * r_delta - 0.01)
     fh = np.floor((smin + rad - start) * r_delta + 0.01) + 1.0
     nlo = np.where(ok, fl, 0.0).astype(np.int64); nhi = np.where(ok, fh, 0.0).astype(np.int64)
