@@ -575,6 +575,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
         const bool std_shape = tierNW[k] == 4 && tierW[k] == 2048 && tierPW[k] == 1024;      // the kernels compiled with these as constants
+        const bool std_shape2 = tierNW[k] == 8 && tierW[k] == 8192 && tierPW[k] == 4096;
         const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
 #define STMPC_LAUNCH_R(L, FD, KT_, FM, SG, RS)                                                                \
         do {                                                                                                  \
@@ -591,6 +592,13 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 4>), grid, block, lds, lst, a);        \
         } while (0)
+#define STMPC_LAUNCH_R88(L, FD, KT_, FM, SG, RS)                                                              \
+        do {                                                                                                  \
+            if (lds > 48 * 1024)                                                                              \
+                HIPCHK(hipFuncSetAttribute((const void *)k_solve<L, false, FD, KT_, FM, SG, RS, 88>,          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 88>), grid, block, lds, lst, a);       \
+        } while (0)
 #define STMPC_LAUNCH_R0(L, FD, KT_, FM, SG)                                                                   \
         do {                                                                                                  \
             if constexpr (L) { if (std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 0); else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0); } \
@@ -602,6 +610,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
             if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
                 if (resume && k == 0 && std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
                 else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
+                else if (resume && k == 1 && std_shape2) STMPC_LAUNCH_R88(L, FD, KT_, FM, SG, 2);             \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
                 else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                     \
             } else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                       \
@@ -620,6 +629,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 #undef STMPC_LAUNCH_S
 #undef STMPC_LAUNCH_R
 #undef STMPC_LAUNCH_R4
+#undef STMPC_LAUNCH_R88
 #undef STMPC_LAUNCH_R0
         return STMPC_OK;
     };

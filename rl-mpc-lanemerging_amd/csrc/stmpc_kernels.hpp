@@ -557,7 +557,15 @@ __device__ __attribute__((noinline)) void ckpt_load(const unsigned char *ck, int
 }
 
 // RES: 0 no checkpointing, 1 this tier saves a layer it cannot build (first window), 2 this tier may continue from one
-// NWX: the most waves per workgroup the instantiation serves (list segments are searched with NWX - 1 compares)
+// NWX selects the workgroup shape an instantiation is compiled for: 8 = any (up to 8 waves, window sizes from SolveArgs);
+// 4 = the standard first window (exactly 4 waves, 2048 cells, 1024 penalty entries); 88 = the standard second window (exactly
+// 8 waves, 8192 cells, 4096 penalty entries).  The fixed shapes have their sizes as immediates and search the list segments
+// with one compare per wave they really have.
+template <int NWX> struct WgShape {
+    static constexpr bool fixed = (NWX == 4 || NWX == 88);
+    static constexpr int waves = (NWX == 4) ? 4 : 8;                 // (most, or exactly when fixed)
+    static constexpr int W = (NWX == 4) ? 2048 : 8192, PW = (NWX == 4) ? 1024 : 4096;
+};
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
                        u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
@@ -567,11 +575,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int NW = (NWX == 4) ? 4 : (int)(blockDim.x >> 6);          // (NWX == 4 is only launched with exactly four waves)
+    typedef WgShape<NWX> SH;
+    const int NW = SH::fixed ? SH::waves : (int)(blockDim.x >> 6);
     const int per = NW * 64;
-    // (NWX == 4: the standard first window -- 2048 cells, 1024 penalty entries -- with its sizes as immediates)
-    const int W = (NWX == 4) ? 2048 : a.W, WM = W - 1;
-    const int PW = (NWX == 4) ? 1024 : a.PW, PWM = PW - 1;
+    const int W = SH::fixed ? SH::W : a.W, WM = W - 1;
+    const int PW = SH::fixed ? SH::PW : a.PW, PWM = PW - 1;
     const int H = p.H, S = ep.S, e = ep.e;
     const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
@@ -746,19 +754,19 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
         M::barrier();        // S1
         STMPC_PH(2);                    // 2: scan + S1
-        int segbase[NWX + 1];
+        int segbase[SH::waves + 1];
         segbase[0] = 0;
 #pragma unroll
-        for (int w = 0; w < NWX; ++w)                 // wave-uniform: keep the boundaries in scalar registers
+        for (int w = 0; w < SH::waves; ++w)           // wave-uniform: keep the boundaries in scalar registers
             segbase[w + 1] = segbase[w] + __builtin_amdgcn_readfirstlane(w < NW ? sh.cnt[w] : 0);
-        const int nlist = segbase[NWX];
+        const int nlist = segbase[SH::waves];
         auto list_at = [&](int g) -> int {                   // g-th selected cell of the layer, descending
             int w = 0;
 #pragma unroll
-            for (int k = 1; k < NWX; ++k) w += (g >= segbase[k]) ? 1 : 0;
+            for (int k = 1; k < SH::waves; ++k) w += (g >= segbase[k]) ? 1 : 0;
             int basew = segbase[0];
 #pragma unroll
-            for (int k = 1; k < NWX; ++k) basew = (w == k) ? segbase[k] : basew;
+            for (int k = 1; k < SH::waves; ++k) basew = (w == k) ? segbase[k] : basew;
             return (int)M::ld16(&list[w * cpw * 64 + (g - basew)]);
         };
         total_nodes += nlist;
@@ -1062,7 +1070,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
     const DevP &p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int W = (NWX == 4) ? 2048 : a.W, WM = W - 1;
+    const int W = WgShape<NWX>::fixed ? WgShape<NWX>::W : a.W, WM = W - 1;
     const int H = p.H;
     Ep ep;
     if constexpr (GRID) {
@@ -1252,8 +1260,8 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;
-    const int W = (NWX == 4) ? 2048 : a.W;
-    const int PWc = (NWX == 4) ? 1024 : a.PW;
+    const int W = WgShape<NWX>::fixed ? WgShape<NWX>::W : a.W;
+    const int PWc = WgShape<NWX>::fixed ? WgShape<NWX>::PW : a.PW;
     unsigned char *base;
     int *chunk_cnt;
     // dynamic LDS: [vehicle table][chunk counters][cell arrays (LDS tiers only)]
