@@ -18,9 +18,14 @@ typedef struct {
     int cap;           /* > 0 with band > 0: the band adapts to keep ~cap nodes per layer (kernel's rule) */
     int twin;          /* > 0: target window cells of a single-wave beam pass: lowest sources whose targets do not fit are dropped */
     int filt;          /* 1: count only candidate edges whose quadratic part can stay within U (exact-pass filter emulation) */
+    int divchunk;      /* > 0 with band > 0: besides the band, the LOWEST reached cell of every divchunk-cell block whose key is within divmult x band */
+    double divmult;
+    int sections;      /* hmode 7: number of position sections with their own band */
 } lab_cfg;
 
-typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; } lab_out;
+typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; double lay_kmin[64], lay_band[64], watch_c[64]; int watch_sel[64]; } lab_out;
+static __thread const int *lab_watch = 0;   /* optional: cells of a path to watch (set through lab_set_watch) */
+void lab_set_watch(const int *w) { lab_watch = w; }
 
 int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_values, int S, const double *t_values, int H,
              double v0, double a0, const double *distances, double d_w, double v_w, double a_w, double j_w, double v_des,
@@ -51,7 +56,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             double C = cur_c[s];
             if (!(C < INFINITY) || C > U) continue;
             double key = C;
-            if (cfg->hmode) { double v = (s_values[s] - cur_p1[s]) / delta_t; double D = v_des - v; key = C + kh * D * D; }
+            if (cfg->hmode && cfg->hmode < 7) { double v = (s_values[s] - cur_p1[s]) / delta_t; double D = v_des - v; key = C + kh * D * D; }
             ents[cnt].key = key; ents[cnt].s = s; cnt++;
             if (key < kmin) kmin = key;
         }
@@ -70,8 +75,56 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
                 if (ng > 0) { f = half / ng; bandg *= (f < 1.0 ? f : sqrt(f)); bandg = bandg > cfg->band ? cfg->band : (bandg < 0.02 * cfg->band ? 0.02 * cfg->band : bandg); }
             }
         } else
+        if (cfg->band > 0 && cfg->hmode == 8) {
+            /* fixed band, then every k-th selected node (position order) so that at most cap remain */
+            int m = 0; for (int i = 0; i < cnt; i++) if (ents[i].key <= kmin + cfg->band) ents[m++] = ents[i]; cnt = m;
+            if (cfg->cap > 0 && cnt > cfg->cap) { int k = (cnt + cfg->cap - 1) / cfg->cap; m = 0; for (int i = 0; i < cnt; i += k) ents[m++] = ents[i]; cnt = m; }
+        } else
+        if (cfg->band > 0 && cfg->hmode == 7) {
+            /* per-section steering: the live window is cut into `twin` equal position ranges (the kernel: one per wave); each keeps its own band
+             * (relative to the layer's global minimum) and steers it towards cap / twin nodes */
+            static __thread double bq[16]; const int Q = cfg->sections > 0 && cfg->sections <= 16 ? cfg->sections : 4;
+            if (t == 0) for (int q = 0; q < Q; q++) bq[q] = cfg->band;
+            int cq[16] = {0}; int m = 0; const int span_ = hi_w - lo_w > 0 ? hi_w - lo_w : 1;
+            /* sections follow the kernel's chunking: 64-cell chunks from the top, ceil(nch / Q) chunks per section */
+            const int top0 = (hi_w + 63) & ~63, nch = (top0 - (lo_w & ~63)) >> 6, cpw = (nch + Q - 1) / Q; (void)span_;
+            for (int i = 0; i < cnt; i++) {
+                int ch = (top0 - 1 - ents[i].s) >> 6, q = ch / (cpw > 0 ? cpw : 1); if (q >= Q) q = Q - 1;
+                if (cur_c[ents[i].s] <= kmin + bq[q]) { cq[q]++; ents[m++] = ents[i]; }
+            }
+            cnt = m;
+            if (cfg->cap > 0) for (int q = 0; q < Q; q++) if (cq[q] > 0) { double f = (double)cfg->cap / (double)Q / (double)cq[q]; bq[q] *= (f < 1.0 ? f : sqrt(f)); bq[q] = bq[q] > cfg->band ? cfg->band : (bq[q] < 0.05 * cfg->band ? 0.05 * cfg->band : bq[q]); }
+        } else
+        if (cfg->band > 0 && cfg->divchunk < 0) {
+            /* wide-and-coarse: every cell within the steered (tight) band, plus every stride-th cell within the FULL band; the tight band
+             * is steered towards cap/2 nodes, the stride (power of two, at most -divchunk) towards cap nodes in all */
+            static __thread int stride_; if (t == 0) stride_ = 1;
+            int m = 0, tight = 0;
+            for (int i = 0; i < cnt; i++) {
+                int in_t = ents[i].key <= kmin + bandt, in_w = ents[i].key <= kmin + cfg->band && (ents[i].s % stride_) == 0;
+                tight += in_t;
+                if (in_t || in_w) ents[m++] = ents[i];
+            }
+            cnt = m;
+            if (cfg->cap > 0 && tight > 0) { double f = 0.5 * (double)cfg->cap / (double)tight; bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > cfg->band ? cfg->band : (bandt < 0.02 * cfg->band ? 0.02 * cfg->band : bandt); }
+            if (cfg->cap > 0) { if (cnt > cfg->cap && stride_ < -cfg->divchunk) stride_ *= 2; else if (cnt < cfg->cap / 2 && stride_ > 1) stride_ /= 2; }
+        } else
+        if (cfg->band > 0 && cfg->divchunk > 0) {
+            int m = 0, inband = 0, lastblk = -1;
+            for (int i = 0; i < cnt; i++) {          /* ents ascending in s */
+                int blk = ents[i].s / cfg->divchunk;
+                int take = ents[i].key <= kmin + bandt;
+                if (take) inband++;
+                if (!take && blk != lastblk && ents[i].key <= kmin + cfg->divmult * cfg->band) take = 1;     /* first (lowest) reached cell of its block */
+                if (blk != lastblk && (take || ents[i].key <= kmin + cfg->divmult * cfg->band)) lastblk = blk;
+                if (take) ents[m++] = ents[i];
+            }
+            cnt = m;
+            if (cfg->cap > 0 && inband > 0) { double f = (double)cfg->cap / (double)inband; bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > cfg->band ? cfg->band : (bandt < 0.05 * cfg->band ? 0.05 * cfg->band : bandt); }
+        } else
         if (cfg->band > 0) { int m = 0; for (int i = 0; i < cnt; i++) if (ents[i].key <= kmin + bandt) ents[m++] = ents[i]; cnt = m;
-            if (cfg->cap > 0 && cnt > 0) { double f = (double)cfg->cap / (double)cnt; bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > cfg->band ? cfg->band : (bandt < 0.05 * cfg->band ? 0.05 * cfg->band : bandt); } }
+            if (cfg->cap > 0 && cnt > 0) { double f = (double)cfg->cap / (double)cnt; const double up = (cfg->divchunk == 0 && cfg->divmult > 1.0) ? cfg->divmult * cfg->band : cfg->band;   /* divmult doubles as the band's upper limit factor */
+                bandt = bandt * (f < 1.0 ? f : sqrt(f)); bandt = bandt > up ? up : (bandt < 0.05 * cfg->band ? 0.05 * cfg->band : bandt); } }
         if (cfg->beamK > 0 && cnt > cfg->beamK && cfg->hmode == 3) {
             /* mixed beam: K/2 smallest by f = g + h, then K/2 smallest by g among the rest */
             qsort(ents, cnt, sizeof(lab_ent), lab_cmp);
@@ -83,6 +136,8 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
         if (cfg->beamK > 0 && cnt > cfg->beamK) { qsort(ents, cnt, sizeof(lab_ent), lab_cmp); cnt = cfg->beamK; }
         /* restore ascending-s order so ties resolve like the reference */
         if (cfg->beamK > 0) { for (int i = 1; i < cnt; i++) { lab_ent e = ents[i]; int j = i - 1; while (j >= 0 && ents[j].s > e.s) { ents[j + 1] = ents[j]; j--; } ents[j + 1] = e; } }
+        out->lay_kmin[t] = kmin; out->lay_band[t] = bandt;
+        if (lab_watch) { int w = lab_watch[t]; out->watch_c[t] = (w >= 0 && w < S) ? cur_c[w] : -1.0; out->watch_sel[t] = 0; for (int i = 0; i < cnt; i++) if (ents[i].s == w) out->watch_sel[t] = 1; }
         if (cnt == 0) break;
         if (cnt > maxlayer) maxlayer = cnt;
         rounds64 += (cnt + 63) / 64;
