@@ -1353,7 +1353,9 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
                             if (e < 0) e = claim(1);
                             break;
                         }
-                        if (wall_clock64() - t_begin > a.wait_ticks) break;
+                        // (a consumer lives for the first launch's tail, a few ms: a tenth of the bound on a published entry -- 20 ms -- is
+                        // ample, and caps what a mis-scheduled side launch can cost when several batches are in flight)
+                        if (wall_clock64() - t_begin > a.wait_ticks / 10) break;
                         __builtin_amdgcn_s_sleep(64);
                     }
                 }
