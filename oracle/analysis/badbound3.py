@@ -9,11 +9,9 @@ cost = np.load('gpurun_out/times_ub_cost.npy'); bt = np.load('gpurun_out/times_u
 idx = [i for i in range(1000) if bt[i] == 39]
 variants = {
     "now: hard b1800 cap300": [dict(band=1800.0, cap=300, hs=1), dict(band=7200.0, cap=300, hs=0)],
-    "sect4 b1800 cap300": [dict(band=1800.0, cap=300, hs=1, hmode=7, sections=4), dict(band=7200.0, cap=300, hs=0, hmode=7, sections=4)],
-    "sect4 b3600 cap300": [dict(band=3600.0, cap=300, hs=1, hmode=7, sections=4), dict(band=7200.0, cap=300, hs=0, hmode=7, sections=4)],
-    "sect8 b3600 cap300": [dict(band=3600.0, cap=300, hs=1, hmode=7, sections=8), dict(band=7200.0, cap=300, hs=0, hmode=7, sections=8)],
-    "sect4 b3600 cap400": [dict(band=3600.0, cap=400, hs=1, hmode=7, sections=4), dict(band=7200.0, cap=400, hs=0, hmode=7, sections=4)],
-    "sect4 b7200 cap300": [dict(band=7200.0, cap=300, hs=1, hmode=7, sections=4), dict(band=7200.0, cap=300, hs=0, hmode=7, sections=4)],
+    "cap450": [dict(band=1800.0, cap=450, hs=1), dict(band=7200.0, cap=450, hs=0)],
+    "cap600": [dict(band=1800.0, cap=600, hs=1), dict(band=7200.0, cap=600, hs=0)],
+    "b2700 cap450": [dict(band=2700.0, cap=450, hs=1), dict(band=7200.0, cap=450, hs=0)],
 }
 for name, atts in variants.items():
     rel = []; nodes = 0; second = 0

@@ -482,6 +482,7 @@ struct PassOut {
 #define STMPC_MAXWAVES 8
 struct WgShared {
     int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
+    int agg[4];                           // the same over the whole workgroup (LDS atomics; reset after every round that used them)
     u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
     int best_n[STMPC_MAXWAVES];
     u64 min_tot[STMPC_MAXWAVES];          // per-wave cheapest relaxed candidate (PASS_BOUND)
@@ -608,6 +609,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         ckpt_load<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
         if (tid == 0) sh.flags = fl;
     } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
+    if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; }
     M::barrier();
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false; out.nodes = 0; out.maxspan = 0;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
@@ -910,19 +912,28 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (relax) {
                 const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
                 const int fan_w = wave_max_i(hi - lo);
-                if (lane == 0) { sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w; }
+                if (lane == 0) {
+                    sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w;
+                    atomicMin(&sh.agg[0], clo_w); atomicMax(&sh.agg[1], chi_w); atomicMax(&sh.agg[2], fan_w);
+                }
             }
             M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
             STMPC_PH(5);                // 5: wave reductions + B1
-            // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer.
+            // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer -- nearly always all
+            // of them, which the workgroup-wide figures show at once; the per-wave walk is the rare fallback.
             int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0;
+            bool agg_used = false;
             if (relax) {
-                kw = 0;
-                for (int w = 0; w < NW; ++w) {
-                    const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
-                    const int l2 = l_ < clo ? l_ : clo, h2 = h_ > chi ? h_ : chi;
-                    if (w > 0 && h2 > l2 && (((h2 + 63) & ~63) - (l2 & ~63)) > PW) break;
-                    clo = l2; chi = h2; fan = f_ > fan ? f_ : fan; kw = w + 1;
+                clo = sh.agg[0]; chi = sh.agg[1]; fan = sh.agg[2];
+                agg_used = chi > clo;           // (untouched initial values otherwise: nothing to reset)
+                if (chi > clo && (((chi + 63) & ~63) - (clo & ~63)) > PW) {
+                    kw = 0; clo = 0x7fffffff; chi = 0; fan = 0;
+                    for (int w = 0; w < NW; ++w) {
+                        const int l_ = sh.red[w * 4 + 0], h_ = sh.red[w * 4 + 1], f_ = sh.red[w * 4 + 2];
+                        const int l2 = l_ < clo ? l_ : clo, h2 = h_ > chi ? h_ : chi;
+                        if (w > 0 && h2 > l2 && (((h2 + 63) & ~63) - (l2 & ~63)) > PW) break;
+                        clo = l2; chi = h2; fan = f_ > fan ? f_ : fan; kw = w + 1;
+                    }
                 }
                 rstep = (64 * kw) >> gsh;
             }
@@ -932,7 +943,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (!relax) continue;
             const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
             const int a_k = list_at(rlast);                      // lowest source of this round (uniform)
-            if (clo >= chi) { M::barrier(); continue; }       // (keeps sh.red stable until everyone has read it)
+            if (clo >= chi) {                                 // (keeps sh.red / sh.agg stable until everyone has read them)
+                M::barrier();
+                if (agg_used) { if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; } M::barrier(); }     // (fallback walk that took an empty wave only)
+                continue;
+            }
             const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
             // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
             // below a_k, the lowest source of this round (lower cells may hold sources that are still unread;
@@ -961,6 +976,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (need_hi > pv_hi) repen(pv_hi, need_hi);
             }
             M::barrier();     // B2: next-layer cells of this round are initialised
+            // (everyone has read the workgroup-wide figures; the next round's atomics come after this round's B3)
+            if (agg_used && tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; }
             STMPC_PH(7);                // 7: cell initialisation (penalties) + B2
 
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
