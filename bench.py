@@ -273,7 +273,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                 "kernel": "stmpc::k_solve<true,false,...> (LDS lattice DP; one launch per LDS window tier, summed per step)",
                 "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve, "bytes_per_launch": bytes_per_solve * n,
                 "note": "algorithmic HBM bytes are %d B/solve (SURVEY 8d): the path is fp64-VALU/LDS-latency bound, not HBM bound; "
-                        "see fp64_valu for the bound that applies" % bytes_per_solve}
+                        "see fp64_valu and issue for the bounds that apply" % bytes_per_solve}
 
     metric = {"h40a21": "MPC solves/sec (H=40,A=21,K=6)", "default": "MPC solves/sec (reference default H=18,S=3001,K=6)",
               "control": "st.do_st_control commanded speeds/sec (reference default H=18,S=3001,K=6, QP re-sampling to the 0.2 s tick)"}[args.workload]
@@ -365,6 +365,14 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                             "kernel_nodes_per_solve": nodes_exec, "kernel_candidates_per_node": cand_per_node,
                             "note": "flops = 27/edge + 26/node (+6*K per touched cell for the full DP) + 40*K*H for the predictor (SURVEY 8d); "
                                     "reference_algorithm_* prices the heap Dijkstra's own node/edge counts, which is the useful work"}
+        # the unit that is actually half-busy: instruction issue.  Wave-instructions per step from the committed counter pass (same command,
+        # same batch), 4 cycles of a SIMD per VALU wave-instruction, 1024 SIMDs at 2.4 GHz for this run's kernel time.
+        vi, si = measured.get("per_step_SQ_INSTS_VALU"), measured.get("per_step_SQ_INSTS_SALU")
+        if vi and dp_ms > 0 and n == 4096:
+            out["issue"] = {"valu_wave_instructions_per_step": vi, "salu_wave_instructions_per_step": si,
+                            "valu_issue_slots_per_step": 1024 * dp_ms * 1e-3 * 2.4e9 / 4.0,
+                            "valu_busy_frac": vi * 4.0 / (1024 * dp_ms * 1e-3 * 2.4e9),
+                            "source": "profiles/r2/measured.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., scripts/profile_gpu.sh), kernel time of this run"}
     return out
 
 
