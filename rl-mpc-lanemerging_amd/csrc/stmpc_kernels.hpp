@@ -806,6 +806,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // still fills the workgroup's lanes: the candidate loop runs ceil(fan / G) slots instead of fan.  All lanes of a
         // group load the same source (LDS broadcast) and derive the same range; which lane evaluates a candidate
         // does not matter to the staged minimum below.
+        const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
             // (chosen per round: the short last round of a wide layer is spread as well)
             int gsh = 0;
@@ -815,7 +816,6 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             const int srcidx = r0 + (tid >> gsh);
             const bool inlist = srcidx < nlist;
             const int i = inlist ? list_at(srcidx) : 0;
-            const int smin = list_at(nlist - 1);                 // lowest source of the layer
             u64 cb = INF_BITS;
             unsigned h = 0u;
             if (inlist) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
