@@ -21,6 +21,7 @@ typedef struct {
     int divchunk;      /* > 0 with band > 0: besides the band, the LOWEST reached cell of every divchunk-cell block whose key is within divmult x band */
     double divmult;
     int sections;      /* hmode 7: number of position sections with their own band */
+    int switch_t;      /* > 0 with band > 0: layers before switch_t expand everything <= U (the exact pass), the band applies from switch_t on */
 } lab_cfg;
 
 typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; double lay_kmin[64], lay_band[64], watch_c[64]; int watch_sel[64]; } lab_out;
@@ -75,6 +76,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
                 if (ng > 0) { f = half / ng; bandg *= (f < 1.0 ? f : sqrt(f)); bandg = bandg > cfg->band ? cfg->band : (bandg < 0.02 * cfg->band ? 0.02 * cfg->band : bandg); }
             }
         } else
+        if (cfg->band > 0 && cfg->switch_t > 0 && t < cfg->switch_t) { /* exact part: everything <= U */ } else
         if (cfg->band > 0 && cfg->hmode == 8) {
             /* fixed band, then every k-th selected node (position order) so that at most cap remain */
             int m = 0; for (int i = 0; i < cnt; i++) if (ents[i].key <= kmin + cfg->band) ents[m++] = ents[i]; cnt = m;
@@ -162,7 +164,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
         }
         for (int q = q0; q < cnt; q++) {
             int s = ents[q].s; double C = cur_c[s];
-            nodes++;
+            nodes++; if (cfg->switch_t > 0 && t >= cfg->switch_t) out->tspan_over++;   /* (switch mode: nodes of the completion part) */
             double sv = s_values[s], mn, mx; int lo, hi;
             orc_next_s_range(sv, cur_p1[s], cur_p2[s], delta_t, j_min, j_max, a_min, a_max, v_max, &mn, &mx);
             orc_range_indices(start_s, delta_s, mn, mx, &lo, &hi);
