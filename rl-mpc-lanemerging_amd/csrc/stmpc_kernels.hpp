@@ -782,6 +782,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
         }
         if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
+        const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         if constexpr (MODE == PASS_EXACT) {
             u64 bb = ~0ull; int bn = 0x7fffffff;
             for (int w = 0; w < NW; ++w) {
@@ -792,7 +793,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (RES == 1 && relax && t > 0) {
                 // will layer t+1 fit?  Every target lies within maxshift cells above its source, so the live span of
                 // the layer about to be built is at most (highest source + maxshift) - lowest source.
-                const int top_src = list_at(0), low_src = list_at(nlist - 1);
+                const int top_src = list_at(0), low_src = smin;
                 if (top_src + a.maxshift - low_src > W) {
                     ckpt_save<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
                     return 2;
@@ -806,7 +807,6 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // still fills the workgroup's lanes: the candidate loop runs ceil(fan / G) slots instead of fan.  All lanes of a
         // group load the same source (LDS broadcast) and derive the same range; which lane evaluates a candidate
         // does not matter to the staged minimum below.
-        const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
             // (chosen per round: the short last round of a wide layer is spread as well)
             int gsh = 0;
