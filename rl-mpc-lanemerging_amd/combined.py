@@ -18,18 +18,11 @@ from .prediction import HighwayState, pack_states
 
 
 def get_ego_speed_from_jerk(current_speed, current_acceleration, jerk):
-    # control.py:160-171
-    new_acceleration = current_acceleration + jerk * Settings.TICK_LENGTH
-    if new_acceleration > Settings.MAX_POSITIVE_ACCELERATION:
-        new_acceleration = Settings.MAX_POSITIVE_ACCELERATION
-    if new_acceleration < Settings.MAX_NEGATIVE_ACCELERATION:
-        new_acceleration = Settings.MAX_NEGATIVE_ACCELERATION
-    new_speed = current_speed + new_acceleration * Settings.TICK_LENGTH
-    if new_speed > Settings.MAX_SPEED:
-        new_speed = Settings.MAX_SPEED
-    if new_speed < 0:
-        new_speed = 0
-    return new_speed
+    """Speed after one tick of constant jerk, acceleration and speed clamped to their limits (the host twin of the
+    first lines of ``k_rollout_step``; same result as control.py:160-171)."""
+    tick = Settings.TICK_LENGTH
+    acc = min(max(current_acceleration + jerk * tick, Settings.MAX_NEGATIVE_ACCELERATION), Settings.MAX_POSITIVE_ACCELERATION)
+    return min(max(current_speed + acc * tick, 0), Settings.MAX_SPEED)
 
 
 REASON_RL, REASON_CRASH, REASON_SPEED, REASON_ROLLOUT, REASON_ST_BETTER = 0, 1, 2, 3, 4

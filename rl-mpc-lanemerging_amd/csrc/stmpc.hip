@@ -170,6 +170,11 @@ struct stmpc_ctx {
     int overlap = -1;              // -1 auto: with the bounded (wide fan-out) search, where overflow is common
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // STMPC_CU_RESERVE=n (multiple of 8, experiment): n compute units are kept out of the first window's launch and host the second
+    // window's workgroups from the start of the step (CU-masked streams); 0 = off
+    int cu_reserve = 0;
+    hipStream_t main_masked = nullptr, aux_reserved = nullptr;
+    hipEvent_t ev_join0 = nullptr, ev_join_r = nullptr;
 };
 
 extern "C" {
@@ -273,6 +278,21 @@ int stmpc_create(stmpc_ctx **out, int device) {
         if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
     }
     if (!c->aux_stream) c->overlap = 0;          // no side stream: the tiers simply run one after the other
+    if (const char *w = getenv("STMPC_CU_RESERVE")) {
+        // Reserved compute units: bit 32a + a + 8j (a = 0..7, j < n/8) of the CU mask.  Whether the driver numbers the mask bits
+        // XCD by XCD or round-robin over the XCDs, every XCD gives up n/8 units and keeps the rest (a queue whose mask leaves an XCD
+        // without units would never get the workgroups the dispatcher assigns to that XCD).
+        int v = atoi(w);
+        if (c->aux_stream && v >= 8 && v <= 128 && v % 8 == 0 && c->num_cu == 256) {
+            uint32_t res[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rest[8];
+            for (int a = 0; a < 8; ++a) for (int j = 0; j < v / 8; ++j) { const int bit = 32 * a + ((a + 8 * j) & 31); res[bit >> 5] |= 1u << (bit & 31); }
+            for (int i = 0; i < 8; ++i) rest[i] = ~res[i];
+            if (hipExtStreamCreateWithCUMask(&c->main_masked, 8, rest) == hipSuccess && hipExtStreamCreateWithCUMask(&c->aux_reserved, 8, res) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_join0, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join_r, hipEventDisableTiming) == hipSuccess)
+                c->cu_reserve = v;
+            else (void)hipGetLastError();
+        }
+    }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         stmpc_destroy(c);
@@ -293,6 +313,10 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
                      &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
     for (DevBuf *b : all) b->release();
+    if (c->main_masked) (void)hipStreamDestroy(c->main_masked);
+    if (c->aux_reserved) (void)hipStreamDestroy(c->aux_reserved);
+    if (c->ev_join0) (void)hipEventDestroy(c->ev_join0);
+    if (c->ev_join_r) (void)hipEventDestroy(c->ev_join_r);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -474,6 +498,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
                   bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
     const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
+    // reserved compute units (experiment, STMPC_CU_RESERVE): the first window's persistent grid covers the remaining units only
+    const bool reserve_cfg = c->cu_reserve > 0 && prune_on && nt >= 2 && tierLds[0] && tierLds[1] && !c->two_phase;
+    if (reserve_cfg) tierGrid[0] = tierGrid[0] / c->num_cu * (c->num_cu - c->cu_reserve);
     for (int k = 0; k < nt; ++k) if (tierGrid[k] > N) tierGrid[k] = N;
     if (resume) {
         // per-episode back-pointers + checkpoints: if the device cannot spare them (a process shared with torch / RCCL), fall
@@ -506,6 +533,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // extra launch, and not with the two-phase schedule (its first launch of tier 0 only bounds)
     const bool overlap = nt >= 2 && tierLds[1] && !(prune_on && c->two_phase) && N > tierGrid[0] &&
                          (c->overlap < 0 ? prune_on != 0 : c->overlap != 0);
+    const bool reserve = reserve_cfg && overlap;
     int *queue1 = overlap ? c->lists.as<int>() + (size_t)N : nullptr;
     const bool split = prune_on && !c->two_phase && c->split && N >= 2 * tierGrid[0];
     unsigned *proxy0 = split ? c->proxy.as<unsigned>() : nullptr;
@@ -560,9 +588,10 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
 
     // one launch of tier k: phase 0 = bound + exact, 1 = bounding pre-passes only, 2 = exact with the stored bounds;
     // side = on the side stream, consuming tier 0's overflow queue while tier 0 is still running
-    auto launch_tier = [&](int k, int phase, bool side) -> int {
-        hipStream_t lst = side ? c->aux_stream : st;
+    auto launch_tier = [&](int k, int phase, bool side, bool on_reserved = false) -> int {
+        hipStream_t lst = side ? (on_reserved ? c->aux_reserved : c->aux_stream) : ((reserve && k == 0) ? c->main_masked : st);
         a.concurrent = side ? 1 : 0;
+        a.always_wait = on_reserved ? 1 : 0;
         a.split = (split && k == 0) ? 1 : 0;
         a.feeds_concurrent = (overlap && k == 0) ? 1 : 0;
         a.prev_grid = side ? tierGrid[0] : 0;
@@ -576,7 +605,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         const size_t lds = tierLdsBytes[k];
         const bool std_shape = tierNW[k] == 4 && tierW[k] == 2048 && tierPW[k] == 1024;      // the kernels compiled with these as constants
         const bool std_shape2 = tierNW[k] == 8 && tierW[k] == 8192 && tierPW[k] == 4096;
-        const dim3 grid(tierGrid[k]), block(64 * tierNW[k]);
+        const dim3 grid(on_reserved ? (tierGrid[k] / c->num_cu > 0 ? tierGrid[k] / c->num_cu : 1) * c->cu_reserve : tierGrid[k]), block(64 * tierNW[k]);
 #define STMPC_LAUNCH_R(L, FD, KT_, FM, SG, RS)                                                                \
         do {                                                                                                  \
             if (lds > 48 * 1024)                                                                              \
@@ -640,7 +669,18 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, N, (const unsigned *)c->proxy.as<unsigned>(), c->order.as<int>());
     }
     for (int k = 0; k < nt; ++k) {
+        if (reserve && k == 0) HIPCHK(hipStreamWaitEvent(c->main_masked, c->ev_fork, 0));
         if ((rc = launch_tier(k, two_phase ? 2 : 0, false))) return rc;
+        if (reserve && k == 0) {
+            // the reserved units host second-window workgroups from the start of the step; the masked streams partition the device, so
+            // these consumers may always wait for the queue (they cannot be holding a unit a producer needs)
+            HIPCHK(hipEventRecord(c->ev_join0, c->main_masked));
+            HIPCHK(hipStreamWaitEvent(c->aux_reserved, c->ev_fork, 0));
+            if ((rc = launch_tier(1, 0, true, true))) return rc;
+            HIPCHK(hipEventRecord(c->ev_join_r, c->aux_reserved));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_join0, 0));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_join_r, 0));
+        }
         if (overlap && k == 0) {
             // tier 1 alongside tier 0: queued on the side stream behind the predictor only; its workgroups start when
             // tier 0's persistent workgroups begin to leave CUs.  The main stream then waits for it, and the ordinary

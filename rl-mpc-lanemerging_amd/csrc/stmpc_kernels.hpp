@@ -425,6 +425,7 @@ struct SolveArgs {
     int concurrent;        // this launch runs alongside the previous tier's and waits for its queue to fill (see k_solve)
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
     int prev_grid;         // workgroups of the producing launch (concurrent consumer: all must be resident, all must finish)
+    int always_wait;       // concurrent consumer on compute units the producers cannot use (CU-masked streams): waiting is always safe
     unsigned long long wait_ticks;   // concurrent consumer: give up waiting after this many 100 MHz ticks
     unsigned *proxy;       // [N] work estimate written by phase 1 (nodes the pre-passes expanded)
     // outputs
@@ -482,7 +483,8 @@ struct PassOut {
 #define STMPC_MAXWAVES 8
 struct WgShared {
     int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
-    int agg[4];                           // the same over the whole workgroup (LDS atomics; reset after every round that used them)
+    int agg[8];                           // the same over the whole workgroup (LDS atomics; reset after every round that used them); the
+                                          // bounding pass alternates between two sets (its rounds have no barrier after the candidates)
     u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
     int best_n[STMPC_MAXWAVES];
     u64 min_tot[STMPC_MAXWAVES];          // per-wave cheapest relaxed candidate (PASS_BOUND)
@@ -596,9 +598,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
     };
     u16 *bp = ep.bp;
-    struct { double kv, ka, kj, invK; bool ok; } nk;        // coefficients of the edge-cost quadratic (see the candidate filter)
+    struct { double kv, ka, kj, invK, K; bool ok; } nk;     // coefficients of the edge-cost quadratic (see the candidate filter)
     nk.kv = p.v_w / dt2; nk.ka = p.a_w / (dt2 * dt2); nk.kj = p.j_w / (dt3 * dt3);
-    nk.invK = 1.0 / (nk.kv + nk.ka + nk.kj);
+    nk.K = nk.kv + nk.ka + nk.kj;
+    nk.invK = 1.0 / nk.K;
     nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
 
     STMPC_PH_DECL
@@ -609,7 +612,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         ckpt_load<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
         if (tid == 0) sh.flags = fl;
     } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
-    if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; }
+    if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; sh.agg[4] = 0x7fffffff; sh.agg[5] = 0; sh.agg[6] = 0; }
     M::barrier();
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false; out.nodes = 0; out.maxspan = 0;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
@@ -628,9 +631,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         u64 my_min_tot = ~0ull;
         u64 thr = ubits;
         if constexpr (MODE == PASS_BOUND) {
-            const double lim = __longlong_as_double((long long)lmin) + bandt;
-            const u64 lb = (u64)__double_as_longlong(lim);
-            if (lb < thr) thr = lb;
+            // (cells of this pass hold (fp32 cost) << 32 | history, see below: unsigned order = cost order)
+            const float lim = __uint_as_float((unsigned)(lmin >> 32)) + (float)bandt;
+            thr = ((u64)__float_as_uint(lim) << 32) | 0xffffffffull;
         }
         // obstructing vehicles of layer t+1 (wave-uniform): kept in scalar registers when KT > 0
         int nact = 0;
@@ -694,10 +697,22 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
                     }
                 }
-                if constexpr (MODE == PASS_BOUND) { if (hardsoft && d < p.min_allowed) blocked = true; }
+                if constexpr (MODE == PASS_BOUND) {
+                    // single-precision penalty (the gap itself and the zone test stay exact): one v_rcp_f32 instead of an IEEE division
+                    if (hardsoft && d < p.min_allowed) blocked = true;
+                    const bool close = d < p.min_allowed;
+                    const float den = (float)(close ? dmax_py(d, 1.0) : d);
+                    const float pf = (float)p.d_w * ((close ? 1000000.0f : 1.0f) * __builtin_amdgcn_rcpf(den));
+                    pv = blocked ? -1.0 : (double)pf;
+                } else
                 pv = blocked ? -1.0 : dev_weighted_penalty(d, p.min_allowed, p.d_w);
             }
             return pv;
+        };
+        float *const penf = (float *)pen;                     // the bounding pass keeps its penalties in single precision (same buffer, PW entries)
+        auto st_pen = [&](int n, double v) {
+            if constexpr (MODE == PASS_BOUND) __hip_atomic_store(&penf[n & PWM], (float)v, __ATOMIC_RELAXED, M::SCOPE);
+            else M::stf(&pen[n & PWM], v);
         };
         // pen[] is a circular buffer of PW cells; [pv_lo, pv_hi) is the range of cells whose entry is current
         int pv_lo = 0, pv_hi = 0;
@@ -711,13 +726,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         };
         auto init_cells = [&](int from, int to) {            // new next-layer cells: penalty + "not reached"
             for (int n = from + tid; n < to; n += per) {
-                M::stf(&pen[n & PWM], cell_penalty(n));
+                st_pen(n, cell_penalty(n));
                 M::st64(&cost[n & WM], INF_BITS);
             }
             note_written(from, to);
         };
         auto repen = [&](int from, int to) {                 // penalty entries that were evicted and are needed again
-            for (int n = from + tid; n < to; n += per) M::stf(&pen[n & PWM], cell_penalty(n));
+            for (int n = from + tid; n < to; n += per) st_pen(n, cell_penalty(n));
             note_written(from, to);
         };
 
@@ -807,7 +822,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // still fills the workgroup's lanes: the candidate loop runs ceil(fan / G) slots instead of fan.  All lanes of a
         // group load the same source (LDS broadcast) and derive the same range; which lane evaluates a candidate
         // does not matter to the staged minimum below.
-        for (int r0 = 0, rstep = per; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep) {
+        for (int r0 = 0, rstep = per, rpar = 0; r0 < nlist && (relax || MODE == PASS_EXACT); r0 += rstep, ++rpar) {
+            const int ab = (MODE == PASS_BOUND) ? ((rpar & 1) << 2) : 0;      // set of workgroup-wide figures this round uses
             // (chosen per round: the short last round of a wide layer is spread as well)
             int gsh = 0;
             if (relax) { while (gsh < a.gsh_max && ((nlist - r0) << (gsh + 1)) <= per) ++gsh; }
@@ -818,9 +834,16 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             const int i = inlist ? list_at(srcidx) : 0;
             u64 cb = INF_BITS;
             unsigned h = 0u;
-            if (inlist) { cb = M::ld64(&cost[i & WM]); h = M::ld32(&hist[i & WM]); }
+            if (inlist) {
+                cb = M::ld64(&cost[i & WM]);
+                if constexpr (MODE == PASS_BOUND) h = (unsigned)cb;       // the bounding pass keeps the history in the cell's low word
+                else h = M::ld32(&hist[i & WM]);
+            }
             double sv = 0.0, p1 = 0.0, p2 = 0.0;
-            const double C = __longlong_as_double((long long)cb);
+            const double C = __longlong_as_double((long long)cb);            // (PASS_EXACT)
+            const float Cf = __uint_as_float((unsigned)(cb >> 32));           // (PASS_BOUND)
+            double q_smin = 0.0;      // PASS_BOUND: minimiser of the edge-cost quadratic of this source and
+            float q_base = 0.0f;      //             its cost + the quadratic's minimum, in single precision
             int lo = 0, hi = 0;
             unsigned key = 0u;        // what a target won by this source stores: i << 16 | p1 index
             int pr = 0;
@@ -892,7 +915,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         if (nk.ok && hi > lo) {
                             const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
                             const double smin_ = (nk.kv * c_v + nk.ka * c_a + nk.kj * c_j) * nk.invK;
-                            // (no spare cells beyond the interval: the band is a heuristic, and every candidate costs the same ~60 instructions)
+                            // the three quadratic terms of st_cy.pyx:46-50 as ONE quadratic K (s_n - smin_)^2 + emin: what the candidate loop evaluates
+                            q_smin = smin_;
+                            q_base = Cf + (float)(nk.kv * (c_v - smin_) * (c_v - smin_) + nk.ka * (c_a - smin_) * (c_a - smin_) +
+                                                  nk.kj * (c_j - smin_) * (c_j - smin_));
+                            // (no spare cells beyond the interval: the band is a heuristic)
                             const double rad = (double)__builtin_sqrtf((float)(bandt * nk.invK));
                             const double fl = ceil((smin_ - rad - start_s) * r_delta);
                             const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
@@ -902,7 +929,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
                             else if (nlo_ >= hi) { lo = hi - 1; }
                             else { hi = lo + 1; }
-                        }
+                        } else { q_smin = sv; q_base = Cf; }      // (no quadratic part: the edge cost is the gap penalty alone)
                     }
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
@@ -914,7 +941,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 const int fan_w = wave_max_i(hi - lo);
                 if (lane == 0) {
                     sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w;
-                    atomicMin(&sh.agg[0], clo_w); atomicMax(&sh.agg[1], chi_w); atomicMax(&sh.agg[2], fan_w);
+                    atomicMin(&sh.agg[ab + 0], clo_w); atomicMax(&sh.agg[ab + 1], chi_w); atomicMax(&sh.agg[ab + 2], fan_w);
                 }
             }
             M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
@@ -924,7 +951,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0;
             bool agg_used = false;
             if (relax) {
-                clo = sh.agg[0]; chi = sh.agg[1]; fan = sh.agg[2];
+                clo = sh.agg[ab + 0]; chi = sh.agg[ab + 1]; fan = sh.agg[ab + 2];
                 agg_used = chi > clo;           // (untouched initial values otherwise: nothing to reset)
                 if (chi > clo && (((chi + 63) & ~63) - (clo & ~63)) > PW) {
                     kw = 0; clo = 0x7fffffff; chi = 0; fan = 0;
@@ -945,7 +972,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             const int a_k = list_at(rlast);                      // lowest source of this round (uniform)
             if (clo >= chi) {                                 // (keeps sh.red / sh.agg stable until everyone has read them)
                 M::barrier();
-                if (agg_used) { if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; } M::barrier(); }     // (fallback walk that took an empty wave only)
+                if (agg_used) { if (tid == 0) { sh.agg[ab + 0] = 0x7fffffff; sh.agg[ab + 1] = 0; sh.agg[ab + 2] = 0; } M::barrier(); }     // (fallback walk that took an empty wave only)
                 continue;
             }
             const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
@@ -976,12 +1003,47 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (need_hi > pv_hi) repen(pv_hi, need_hi);
             }
             M::barrier();     // B2: next-layer cells of this round are initialised
-            // (everyone has read the workgroup-wide figures; the next round's atomics come after this round's B3)
-            if (agg_used && tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; }
+            // (everyone has read the workgroup-wide figures; the next round's atomics come after this round's B3 -- the bounding pass has
+            // no B3: its next round uses the other set, which was reset a whole round ago)
+            if (agg_used && tid == 0) { sh.agg[ab + 0] = 0x7fffffff; sh.agg[ab + 1] = 0; sh.agg[ab + 2] = 0; }
             STMPC_PH(7);                // 7: cell initialisation (penalties) + B2
 
-            const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
             auto cand = [&](int slot) -> int { return lo + sub + (slot << gsh); };      // cell of this lane's slot-th candidate
+            if constexpr (MODE == PASS_BOUND) {
+                // Bounding pass: any complete path is a bound, so nothing here has to reproduce the reference's arithmetic.  A cell holds
+                // (fp32 accumulated cost) << 32 | key of the offering source, and ONE ds_min_u64 per candidate keeps the cheapest offer together
+                // with its history -- no read-back, no first-setter stage, no barrier after the candidates (the next round's sources lie below
+                // every cell this round can touch, its new cells outside the initialised interval, and its penalty entries are rewritten only
+                // after its B1).  The edge cost is the single quadratic K d^2 + (C + emin) + penalty, d = distance of the candidate from the
+                // source's minimiser: ~12 instructions per candidate instead of ~70.
+                const float Kf = (float)nk.K;
+                const float stepf = (float)(delta * (double)(1 << gsh));
+                float dcur = (hi > lo) ? (float)(sval(lo + sub) - q_smin) : 0.0f;
+                const u64 keyw = (u64)key;
+                for (int cbase = 0; (cbase << gsh) < fan; cbase += 4) {
+                    if (__ballot(cand(cbase) < hi)) {
+                        float pn[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pn[u] = __hip_atomic_load(&penf[cand(cbase + u) & PWM], __ATOMIC_RELAXED, M::SCOPE);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = cand(cbase + u);
+                            const float dd = dcur + (float)u * stepf;
+                            const float tot = __builtin_fmaf(Kf * dd, dd, q_base) + pn[u];
+                            const bool ok = (n < hi) & (pn[u] >= 0.0f);
+                            STMPC_PH_CAND(ok);
+                            if (ok) {
+                                const u64 val = ((u64)__float_as_uint(tot) << 32) | keyw;
+                                if (val < my_min_tot) my_min_tot = val;
+                                (void)M::min64(&cost[n & WM], val);
+                            }
+                        }
+                    }
+                    dcur += 4.0f * stepf;
+                }
+                STMPC_PH(8);
+            } else {
+            const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
             for (int cbase = 0; (cbase << gsh) < fan; cbase += FANMAX) {
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
@@ -1053,6 +1115,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 }
                 STMPC_PH(10);           // 10: stage C (tie repair)
             }
+            }
             if (last_round) break;
         }
 
@@ -1074,6 +1137,12 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     }
     M::barrier();
     STMPC_PH_FLUSH(MODE);
+    if constexpr (MODE == PASS_BOUND) {
+        // the bound: the path's cost as accumulated in single precision (error below 1e-5 relative: <= 2^-23 per operation, ~4 operations
+        // per layer, H layers), inflated beyond that -- any value is safe, the exact pass re-checks
+        const double ub = (double)__uint_as_float((unsigned)(out.best_bits >> 32)) * 1.00002;
+        out.best_bits = (u64)__double_as_longlong(ub);
+    }
     out.pruned = (sh.flags & 1) != 0;
     out.nodes = total_nodes;
     out.maxspan = maxspan;
@@ -1333,7 +1402,7 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
         if (a.tier == 0 && a.feeds_concurrent && tid == 0) atomicAdd(&a.counters[STMPC_CNT_RESIDENT], 1u);
         bool may_wait = false;
         if (a.concurrent && tid == 0)
-            may_wait = __hip_atomic_load(&a.counters[STMPC_CNT_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.prev_grid;
+            may_wait = a.always_wait || __hip_atomic_load(&a.counters[STMPC_CNT_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.prev_grid;
         for (;;) {
             __syncthreads();
             if (tid == 0) {
