@@ -5,8 +5,11 @@ Workload (BASELINE.json configs[1]): batched synthetic merge states, 4096 episod
 H = 40 time layers, fan-out A = 20-21 (SURVEY 8d mapping: S = 7201 cells), K = 6 neighbours, fp64.
 One "step" = one pass of the hot path (traffic prediction -> lattice DP -> path/cost/crash
 outputs) over the batch, inputs already resident in HBM.  With --gpus N every rank solves its own
-block of episodes (BASELINE configs[3]: 65536 episodes over 8 GPUs = 8192 per rank; 4096 per rank
-otherwise) and the ranks all-gather the chosen (action, cost) over RCCL.
+block of episodes and the ranks all-gather the chosen (action, cost) over RCCL.  The per-rank batch is
+the SAME for every N (weak scaling, 4096 unless --episodes says otherwise), so the points of a scaling
+curve differ in nothing but the rank count; BASELINE configs[3] (65536 episodes over 8 GPUs = 8192 per
+rank) is timed as well in every multi-rank run and reported under "config4_shard" (its one-GPU
+counterpart is `--episodes 8192`).
 
 Launch: `python bench.py --gpus N` starts the N ranks itself (one process per GPU); under
 torchrun (WORLD_SIZE set) it joins as one rank.  Prints ONE JSON line on rank 0.
@@ -30,7 +33,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default: 4096; 8192 with --gpus 8 = BASELINE configs[3])")
+    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default 4096 for every --gpus N)")
     ap.add_argument("--workload", choices=["h40a21", "default", "control", "combined"], default="h40a21",
                     help="h40a21: BASELINE workload; default: the reference's own lattice; control: st.do_st_control on the "
                          "reference's lattice (lattice search + QP re-sampling + commanded speed); combined: one tick of the "
@@ -39,6 +42,7 @@ def parse_args():
     ap.add_argument("--pipelined", type=int, default=2, help="also report the throughput with this many batches in flight (one context, stream and "
                     "output buffers each; 0/1 = skip); the headline value is always one batch at a time")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock target per CPU solver (heap, layered) of the cpu_baseline sample")
+    ap.add_argument("--seeds", type=str, default="1000,1,2,3,4", help="state-generator seeds of the seed-median figure (h40a21 / default workloads, one GPU); '' = skip")
     return ap.parse_args()
 
 
@@ -165,7 +169,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
     params = _capi.Params.from_settings(pkg.Settings)
     H, S_nom = _capi.num_t(params), _capi.num_s(params, 0.0)
-    n = args.episodes if args.episodes > 0 else (8192 if world == 8 else 4096)
+    n = args.episodes if args.episodes > 0 else 4096
     K, Kmax = 6, 8
     ego, kc, ox, ov = synth.generate_states(n, k=K, kmax=Kmax, seed=1000 + rank)
 
@@ -228,6 +232,50 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
     torch.cuda.synchronize()
     tier_stats = ctx.stats()
 
+    def timed_other_batch(n_, seed):
+        """Warm-up + args.steps timed steps of another batch (own inputs and outputs, same context); max over ranks; seconds."""
+        e_, k_, x_, v_ = synth.generate_states(n_, k=K, kmax=Kmax, seed=seed)
+        te, tk, tx, tv = (torch.as_tensor(a_, device=dev) for a_ in (e_, k_, x_, v_))
+        o_path = torch.empty((n_, H), dtype=torch.int32, device=dev); o_bt = torch.empty(n_, dtype=torch.int32, device=dev)
+        o_cost = torch.empty(n_, dtype=torch.float64, device=dev); o_pd = torch.empty((n_, H), dtype=torch.float64, device=dev)
+        o_crash = torch.empty(n_, dtype=torch.int32, device=dev)
+        g_ = torch.empty((n_ * world, 2), dtype=torch.float64, device=dev) if use_dist else None
+
+        def step_():
+            ctx.solve_batch_device(params, n_, Kmax, te.data_ptr(), tk.data_ptr(), tx.data_ptr(), tv.data_ptr(), o_path.data_ptr(), o_bt.data_ptr(),
+                                   o_cost.data_ptr(), o_pd.data_ptr(), o_crash.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            if use_dist:
+                sharding.gather_actions(sharding.pack_actions(o_path, o_cost), world, g_, force=True)
+        for _ in range(max(args.warmup, 1)):
+            step_()
+        barrier()
+        c0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_()
+        barrier()
+        el = time.perf_counter() - c0
+        if use_dist:
+            t_ = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el = float(t_.item())
+        return el
+
+    # the headline batch is one draw of the state generator; the step time depends on the draw (its longest searches): median over seeds
+    seed_median = None
+    seeds = [int(x) for x in args.seeds.split(",") if x.strip()] if args.seeds else []
+    if seeds and not use_dist and not control:
+        per_seed = {}
+        for sd in seeds:
+            per_seed[sd] = n * args.steps / (elapsed if sd == 1000 + rank else timed_other_batch(n, sd))
+        seed_median = {"seeds": seeds, "solves_per_s": {str(k_): v_ for k_, v_ in per_seed.items()},
+                       "value_seed_median": float(np.median(list(per_seed.values()))), "min": min(per_seed.values()), "max": max(per_seed.values())}
+    # BASELINE configs[3]: 65536 episodes over 8 GPUs = 8192 per rank, timed in every multi-rank run next to the curve's own per-rank batch
+    config4 = None
+    if use_dist and not control and n != 8192:
+        el4 = timed_other_batch(8192, 2000 + rank)
+        config4 = {"episodes_per_gpu": 8192, "episodes_total": 8192 * world, "value": 8192 * world * args.steps / el4, "unit": "solves/s",
+                   "ms_per_step": el4 / args.steps * 1e3, "note": "BASELINE configs[3] is this with 8 ranks (65536 episodes); not the headline, whose per-rank batch is the same for every N"}
+
     pipelined = None
     if args.pipelined > 1 and not use_dist and not control:
         # serving pattern: consecutive batches on separate streams / contexts / output buffers, so that one batch's tail (its
@@ -267,7 +315,8 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
     bytes_per_solve = 140 + 16 + 4 * H        # state in (K=6) + action/cost/best_t + path_idx[H]
     dp_ms = prof["dp_kernel_ms"] / max(prof["launches"], 1)
     achieved_gbs = bytes_per_solve * n / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "limiting_unit": "VALU instruction issue + LDS round-trip latency of a branchy fp64 DP (see issue, fp64_valu); HBM is reported because BASELINE.json asks for it",
+                "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured.get("hbm_bytes_per_step"),
                 "traffic_source": measured.get("hbm_source"),
                 "kernel": "stmpc::k_solve<true,false,...> (LDS lattice DP; one launch per LDS window tier, summed per step)",
@@ -288,6 +337,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                       "collective": ("all_gather(action,cost) 16 B/episode over RCCL, %d ranks" % world) if use_dist else "none",
                       "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-spawn" if world > 1 else "single")},
            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+           "rccl_ranks": (dist.get_world_size() if use_dist else 0),
            "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
            "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
                      "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]),
@@ -295,6 +345,11 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
 
     if pipelined:
         out["pipelined"] = pipelined
+    if seed_median:
+        out["value_seed_median"] = seed_median["value_seed_median"]
+        out["seed_sweep"] = seed_median
+    if config4:
+        out["config4_shard"] = config4
     if control:
         out["stages"] = {"lattice_search_ms": prof["solve_ms"] / max(prof["launches"], 1),
                          "qp_resampling_ms": ms_per_step - prof["solve_ms"] / max(prof["launches"], 1),
@@ -338,7 +393,8 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
             cpu_rate = 1.0 / (1.0 / cpu_rate + qp_per_solve)
             sample += "; plus the QP stage (oracle/ff_oracle.c, parity-unpinned restatement of cvxopt) timed on 1 thread over %d episodes and divided by the core count" % mq
         out["cpu_baseline"] = {"value": cpu_rate, "unit": "solves/s", "cores": base["threads"], "kind": "port",
-                               "solver": best, "cpu_model": base["cpu_model"], "host_physical_cores": base["physical_cores"],
+                               "solver": best, "reference_algorithm_value": base["heap"]["solves_per_s"],
+                               "reference_algorithm_note": "oracle's binary-heap Dijkstra = the algorithm st_cy.pyx runs; `value` is the faster of that and the layered DP", "cpu_model": base["cpu_model"], "host_physical_cores": base["physical_cores"],
                                "logical_cpus": base["logical_cpus"], "container_cpu_quota": base["cpu_quota"],
                                "per_thread": base[best]["per_thread"], "single_thread": base[best]["single_thread"],
                                "sample": sample}

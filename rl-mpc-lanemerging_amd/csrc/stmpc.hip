@@ -155,7 +155,9 @@ struct stmpc_ctx {
     double fd2_dt = 0, fd2_dt2 = 0, fd2_dt3 = 0, fd2_zl[3] = {0, 0, 0}; bool fd2_ok = false;      // fastdiv2_ok results for the current dt
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
-    int band_cap = 300;            // STMPC_BAND_CAP: nodes per layer the pre-pass steers its band towards (0 = fixed band)
+    int band_cap = 450;            // STMPC_BAND_CAP: nodes per layer the pre-pass steers its band towards (0 = fixed band); 300 until the pre-pass moved to
+                                   // packed single precision (round 3): with candidates at a fifth of their former cost a wider pre-pass pays for itself in
+                                   // tighter bounds (10 state seeds at N=4096: 375-600 all within 2 % of each other and 5 % ahead of 300)
     double band2_mult = 0.0;       // STMPC_BAND2_MULT (0 = default: 4 with the node cap, 5 with a fixed band)
     bool force_general = false;    // STMPC_FORCE_GENERAL=1 (tests)
     bool two_phase = false;        // STMPC_TWO_PHASE=1: bound all episodes first, then solve heaviest-first (measured 6 % slower at N=4096)
@@ -173,6 +175,9 @@ struct stmpc_ctx {
     // STMPC_CU_RESERVE=n (multiple of 8, experiment): n compute units are kept out of the first window's launch and host the second
     // window's workgroups from the start of the step (CU-masked streams); 0 = off
     int cu_reserve = 0;
+    double retry_mult[3] = {1.02, 1.08, 1.3};   // STMPC_RETRY="a,b,c"
+    int retire_cus = 0, retire_at = 75;   // STMPC_RETIRE_CUS=k, STMPC_RETIRE_AT=percent of N: k compute units leave the first launch once fewer than that many tasks are left (see SolveArgs::cu_tab)
+    DevBuf cu_tab;
     hipStream_t main_masked = nullptr, aux_reserved = nullptr;
     hipEvent_t ev_join0 = nullptr, ev_join_r = nullptr;
 };
@@ -278,6 +283,9 @@ int stmpc_create(stmpc_ctx **out, int device) {
         if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
     }
     if (!c->aux_stream) c->overlap = 0;          // no side stream: the tiers simply run one after the other
+    if (const char *w = getenv("STMPC_RETRY")) { double x[3]; if (sscanf(w, "%lf,%lf,%lf", &x[0], &x[1], &x[2]) == 3 && x[0] > 1.0 && x[1] > 1.0 && x[2] > 1.0) for (int i = 0; i < 3; ++i) c->retry_mult[i] = x[i]; }
+    if (const char *w = getenv("STMPC_RETIRE_CUS")) { int v = atoi(w); if (v >= 0 && v < 256) c->retire_cus = v; }
+    if (const char *w = getenv("STMPC_RETIRE_AT")) { int v = atoi(w); if (v >= 1 && v <= 200) c->retire_at = v; }
     if (const char *w = getenv("STMPC_CU_RESERVE")) {
         // Reserved compute units: bit 32a + a + 8j (a = 0..7, j < n/8) of the CU mask.  Whether the driver numbers the mask bits
         // XCD by XCD or round-robin over the XCDs, every XCD gives up n/8 units and keeps the rest (a queue whose mask leaves an XCD
@@ -305,7 +313,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
+    DevBuf *all[] = {&c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
@@ -568,6 +576,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         if (step_max > 0 && a.band * a.band2_mult > 0.7 * step_max) a.band2_mult = fmax(1.0, 0.7 * step_max / a.band);
     }
     a.band_cap = c->band_cap;
+    for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
     a.force_general = c->force_general ? 1 : 0;
     a.gsh_max = c->gsh_max;
     a.zl_dt = c->fd2_zl[0]; a.zl_dt2 = c->fd2_zl[1]; a.zl_dt3 = c->fd2_zl[2];
@@ -583,6 +592,11 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const bool two_phase = a.prune && c->two_phase;      // bound all episodes first, then solve them heaviest-first
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
 
+    if (overlap && split && c->retire_cus > 0 && c->retire_cus < c->num_cu) {
+        if ((rc = c->cu_tab.ensure(1025 * sizeof(unsigned)))) return rc;
+        HIPCHK(hipMemsetAsync(c->cu_tab.p, 0, 1025 * sizeof(unsigned), st));
+        a.cu_tab = c->cu_tab.as<unsigned>(); a.retire_from = c->num_cu - c->retire_cus; a.retire_left = (long long)N * c->retire_at / 100;
+    }
     HIPCHK(hipEventRecord(e1, st));
     if (overlap) HIPCHK(hipEventRecord(c->ev_fork, st));      // the vehicle table and the preset queue are ready
 
@@ -837,6 +851,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     SolveArgs a;
     memset(&a, 0, sizeof a);
     a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.PW = Wg; a.last_tier = 1;
+    for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
     a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0; a.gsh_max = c->gsh_max;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();

@@ -426,6 +426,14 @@ struct SolveArgs {
     int feeds_concurrent;  // this launch's overflow queue is being consumed while it runs: publish entries with release stores
     int prev_grid;         // workgroups of the producing launch (concurrent consumer: all must be resident, all must finish)
     int always_wait;       // concurrent consumer on compute units the producers cannot use (CU-masked streams): waiting is always safe
+    // Handing compute units over to the wider window while the first launch is still running: once fewer than retire_left tasks are
+    // left, the workgroups of the units ranked retire_from and above take no more tasks and exit, so that those units become free
+    // WHOLE (a second-window workgroup needs a unit's whole LDS) while the queue of overflowing episodes is still filling, instead
+    // of quarter by quarter in the launch's tail.  cu_tab: [512] unit keys, [512] rank + 1, [1] units seen.
+    double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
+    unsigned *cu_tab;      // null = off
+    int retire_from;
+    long long retire_left;
     unsigned long long wait_ticks;   // concurrent consumer: give up waiting after this many 100 MHz ticks
     unsigned *proxy;       // [N] work estimate written by phase 1 (nodes the pre-passes expanded)
     // outputs
@@ -1257,7 +1265,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
         // (its answer is usually within a few per cent of the bound, so grow gently first)
         if (attempt >= 3) ubits = INF_BITS;
-        else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * (attempt == 0 ? 1.02 : (attempt == 1 ? 1.08 : 1.3)));
+        else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * (attempt == 0 ? a.retry_mult[0] : (attempt == 1 ? a.retry_mult[1] : a.retry_mult[2])));
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);
     }
     const int best_t = out.best_t, best_n = out.best_n;
@@ -1324,6 +1332,30 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 a.cost[e] = __longlong_as_double((long long)best_bits);
                 if (a.crash) a.crash[e] = (best_t != H - 1 || any_crash) ? 1 : 0;
             }
+        }
+    }
+    return 0;
+}
+
+// Rank of the compute unit this workgroup runs on, in order of first appearance in this launch (0 = first).  The key is the unit's
+// hardware position: XCC_ID and the SE / SH / CU fields of HW_ID.
+__device__ __forceinline__ int cu_rank(unsigned *tab) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned key1 = (((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu)) + 1u;
+    unsigned h = (key1 * 2654435761u) >> 23;
+    for (int probe = 0; probe < 512; ++probe, h = (h + 1u) & 511u) {
+        const unsigned old = atomicCAS(&tab[h], 0u, key1);
+        if (old == 0u) {
+            const unsigned r = atomicAdd(&tab[1024], 1u);
+            __hip_atomic_store(&tab[512 + h], r + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return (int)r;
+        }
+        if (old == key1) {
+            unsigned r1;
+            do { r1 = __hip_atomic_load(&tab[512 + h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (r1 == 0u);
+            return (int)(r1 - 1u);
         }
     }
     return 0;
@@ -1400,6 +1432,8 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
         };
         const unsigned long long t_begin = a.concurrent ? wall_clock64() : 0ull;
         if (a.tier == 0 && a.feeds_concurrent && tid == 0) atomicAdd(&a.counters[STMPC_CNT_RESIDENT], 1u);
+        int my_rank = 0;
+        if (a.tier == 0 && a.cu_tab && tid == 0) my_rank = cu_rank(a.cu_tab);
         bool may_wait = false;
         if (a.concurrent && tid == 0)
             may_wait = a.always_wait || __hip_atomic_load(&a.counters[STMPC_CNT_RESIDENT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)a.prev_grid;
@@ -1413,7 +1447,13 @@ __global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_s
                     // finer-grained tasks pack the persistent workgroups better.  An exact task is handed out at
                     // least N tasks after its bounding task, which is therefore long finished; the wait below only
                     // covers the pathological case.
-                    unsigned w = atomicAdd(&a.counters[0], 1u);
+                    unsigned w = 2u * (unsigned)a.N;
+                    bool retire = false;
+                    if (my_rank > 0) {
+                        const long long left = 2ll * a.N - (long long)__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        retire = my_rank >= a.retire_from && left < a.retire_left;
+                    }
+                    if (!retire) w = atomicAdd(&a.counters[0], 1u);
                     if (w < (unsigned)a.N) { e = a.order ? a.order[w] : (int)w; task_phase = 1; }
                     else if (w < 2u * (unsigned)a.N) {
                         e = a.order ? a.order[w - (unsigned)a.N] : (int)(w - (unsigned)a.N); task_phase = 2;

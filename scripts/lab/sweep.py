@@ -1,5 +1,5 @@
 """In-process sweep of environment knobs on the H40/A21 benchmark batch (one import, one context per spec).
-usage: [STMPC_LIB=...] python scripts/lab/sweep.py <out.json> <n> <seeds: 1000,1,2> "tag:ENV=V,ENV=V" ...
+usage: [STMPC_LIB=...] python scripts/lab/sweep.py <out.json> <n> <seeds: 1000,1,2> "tag:ENV=V;ENV=V" ...
 Per spec and seed: solve time (library events, min / median of 5), window overflows, retries, nodes; the result arrays of every spec
 must equal those of the first spec (every knob is exact), and their digests go to <out.json> so that runs of different builds can
 be compared as well."""
@@ -19,7 +19,7 @@ ref = {}
 rows = []
 for spec in specs:
     tag, _, envs = spec.partition(":")
-    kv = [e.split("=", 1) for e in envs.split(",") if e]
+    kv = [e.split("=", 1) for e in envs.replace(";", " ").split() if e]
     for k_, v_ in kv: os.environ[k_] = v_
     ctx = _capi.Context(0)
     meds = []

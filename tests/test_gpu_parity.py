@@ -277,6 +277,8 @@ def test_bench_forced_rccl_single_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "all_gather" in line["config"]["collective"] and line["value"] > 0
+    assert line["rccl_ranks"] == 1                     # the rank count RCCL itself reports
+    assert line["config4_shard"]["episodes_per_gpu"] == 8192 and line["config4_shard"]["value"] > 0      # BASELINE configs[3]'s per-rank shard, timed in every multi-rank run
 
 
 def test_edge_cases(gpu_ctx, restore_settings):
