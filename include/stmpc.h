@@ -30,8 +30,30 @@
  * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only.
  * Scratch: the wide-lattice solver keeps 2 bytes per lattice cell of the first window and time layer per episode for its
  * back-pointers when it may continue an overflowing search in the next window (N * H * 2048 * 2 B: 0.66 GB for 4096 episodes at
- * H = 40, released by stmpc_destroy); if that allocation fails the solver falls back to per-workgroup storage (restarting instead
- * of continuing overflowing episodes).
+ * H = 40, 1.3 GB for 8192, released by stmpc_destroy) plus a 24 KB checkpoint slot per episode.  The solver takes that only while it
+ * is at most a quarter of the device memory that is free at the time (hipMemGetInfo) and at most 8 GB; otherwise, or if the allocation
+ * fails, it falls back to per-workgroup storage (restarting instead of continuing overflowing episodes) -- results are the same bits.
+ *
+ * Arithmetic contract.  Every operation of the reference's search (st_cy.pyx:34-93) is evaluated as one IEEE-754 fp64 operation in the
+ * reference's order; the library is built with FP contraction off.  Two kinds of division are formed without the hardware's division
+ * sequence, and both return the correctly rounded quotient, i.e. the same bits as `x / d`:
+ *   - by the lattice step (per episode): q = x*r, two residual corrections q += fma(-q, d, x)*r with r = RN(1/d) (Markstein);
+ *   - by dt, dt^2, dt^3 (per launch): fma(x, zh, x*zl) with zh = RN(1/d), zl = RN(1/d - zh), used only after stmpc_fastdiv2_check has
+ *     enumerated every significand of x whose quotient lies within the sequence's error (2^-105 relative) of a rounding midpoint and
+ *     has run the sequence on each of them; a divisor that fails (about one in a hundred; 0.3, 0.09, 0.027 pass) gets the kernels
+ *     that divide.  Precondition of that proof: x*zl must not underflow, |x| >~ 1e-290; the dividends here are lattice coordinate
+ *     differences (multiples of ~1e-2 m up to a few hundred metres, or exactly 0, for which both forms give 0), so this cannot occur.
+ *   Results are bit-identical whichever form runs (STMPC_FASTDIV=0 forces the dividing kernels; the test suite runs both).
+ * The bounding pre-pass that precedes the exact search works in single precision; it only supplies an upper bound that the exact
+ * pass re-checks (a bound that turns out too low is raised and the pass repeated), so it cannot influence any output bit.
+ * Limits the reference does not have: STMPC_QP_NMAX = 64 fine samples in st.finer_fit / st.do_st_control -- the fine grid has
+ * floor((len - 1) * dt / tick) + 1 samples, so e.g. H = 40 with dt / tick = 1.5 (59 samples) is accepted and H = 44 at that ratio
+ * (65) is refused: fine_len = -1 for that state, reported by stmpc_check_error / stmpc_combined_read_state as STMPC_EINVAL;
+ * STMPC_KMAX_LIMIT = 32 vehicles per state; STMPC_S_LIMIT lattice cells (16-bit back-pointers).
+ *
+ * Errors detected on the device (an impossible solver state, a refused QP) are latched in the context: the asynchronous `_device`
+ * entries cannot return them, so call stmpc_check_error at the next point where the host synchronises anyway (stmpc_get_stats,
+ * stmpc_combined_read_state and the host-pointer entries do it themselves).
  */
 #ifndef STMPC_H
 #define STMPC_H
@@ -41,6 +63,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define STMPC_ABI_VERSION 3   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
 
 #define STMPC_OK        0
 #define STMPC_EINVAL   -1   /* bad argument (NULL, size, Kmax/H/S out of range) */
@@ -104,6 +128,8 @@ typedef struct stmpc_ctx stmpc_ctx;
 /* Library / device identification, e.g. "stmpc 0.1 hip gfx950 AMD Instinct MI355X cu=256". */
 const char *stmpc_backend_info(void);
 const char *stmpc_last_error(void);
+/* STMPC_ABI_VERSION the library was built with: a binding compares it with the header it was written against before calling anything else. */
+int stmpc_abi_version(void);
 
 /* Context = one HIP device + its staging/scratch buffers.  device < 0 -> current device. */
 int  stmpc_create(stmpc_ctx **out, int device);
@@ -143,6 +169,12 @@ int stmpc_solve_batch(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
                       double *path_dist, int32_t *crash);
 
 int stmpc_get_stats(stmpc_ctx *ctx, stmpc_stats *out);
+
+/* Synchronises the device and returns (and clears) what the kernels of earlier calls on this context flagged: STMPC_EINTERNAL if a
+ * solver kernel met an impossible state (e.g. a queue entry that never appeared: that episode's output rows are then stale),
+ * STMPC_EINVAL if st.do_st_control could not re-sample a path (more than STMPC_QP_NMAX fine samples: that state's commanded speed is
+ * not valid), else STMPC_OK. */
+int stmpc_check_error(stmpc_ctx *ctx);
 
 /* enable != 0: start timing every subsequent stmpc_solve_batch_device launch with its own HIP events (no host
  * synchronisation is added to the launches).  enable == 0: wait for those launches, sum their device times into
@@ -190,15 +222,21 @@ int stmpc_build_grid(stmpc_ctx *ctx, const stmpc_params *p, const double *state5
  *   mode 0: predict_step_with_ego(selected_speed[i], dt, min_crash_distance)
  *   mode 1: predict_step_without_ego(dt, min_crash_distance)   (selected_speed ignored, may be NULL)
  * state layout as in stmpc_solve_batch but ego is [N][4] = x, y, v, a.  Outputs have the same
- * shapes; crashed [N] receives the crash flag; other_a_out [N][Kmax] (may be NULL) the new_other_accelerations
- * of prediction.py:86-89,97 (the deceleration applied to a following vehicle, else 0) -- what the RL state vector reads
- * (dqn.get_state_vector_from_base_state, dqn.py:400).
+ * shapes; crashed [N] receives the crash flag.  stmpc_predict_batch_acc additionally returns other_a_out [N][Kmax] (may be NULL),
+ * the new_other_accelerations of prediction.py:86-89,97 (the deceleration applied to a following vehicle, else 0) -- what the RL
+ * state vector reads (dqn.get_state_vector_from_base_state, dqn.py:400).  (ABI 2 had given stmpc_predict_batch itself that
+ * trailing parameter; ABI 3 restores its original signature and adds the _acc entry.)
  */
 int stmpc_predict_batch(stmpc_ctx *ctx, const stmpc_params *p, int mode, int N, int Kmax,
                         const double *ego4, const int32_t *k_count, const double *other_x,
                         const double *other_v, const double *selected_speed, double dt,
                         double min_crash_distance, double *ego4_out, double *other_x_out,
-                        double *other_v_out, int32_t *crashed, double *other_a_out);
+                        double *other_v_out, int32_t *crashed);
+int stmpc_predict_batch_acc(stmpc_ctx *ctx, const stmpc_params *p, int mode, int N, int Kmax,
+                            const double *ego4, const int32_t *k_count, const double *other_x,
+                            const double *other_v, const double *selected_speed, double dt,
+                            double min_crash_distance, double *ego4_out, double *other_x_out,
+                            double *other_v_out, int32_t *crashed, double *other_a_out);
 
 #define STMPC_QP_NMAX     64   /* max fine samples of st.finer_fit (one wavefront lane per sample) */
 #define STMPC_QP_MAXITERS 10   /* solvers.options['maxiters'] = 10, st.py:17 */
@@ -309,6 +347,9 @@ int stmpc_sim_view_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, int K
                           double *d_other_x, double *d_other_v, double *d_other_a, void *stream);
 int stmpc_sim_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_sim_cfg *cfg, int N, const double *d_cmd_speed, void *stream);
 int stmpc_sim_read(stmpc_ctx *ctx, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4);
+/* status [N] into a DEVICE array, asynchronously on `stream`: lets a controller loop mask its own per-environment statistics to the
+ * environments that are still running without a host round trip. */
+int stmpc_sim_status_device(stmpc_ctx *ctx, int N, int32_t *d_status, void *stream);
 
 /* Device arithmetic probe used by the parity tests: out[i] = a[i] op b[i] evaluated on the GPU
  * with the kernels' compile flags. op: 0 div, 1 sqrt(a), 2 mul, 3 add, 4 fma(a,a,b*b), 5 the five-operation

@@ -87,7 +87,9 @@ EXPORTS = (
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
     "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
     "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check",
+    "stmpc_abi_version", "stmpc_check_error", "stmpc_predict_batch_acc", "stmpc_sim_status_device",
 )
+ABI_VERSION = 3     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
 QP_NMAX = 64        # STMPC_QP_NMAX
 QP_MAXITERS = 10    # STMPC_QP_MAXITERS (solvers.options['maxiters'], st.py:17)
@@ -116,6 +118,10 @@ def load():
         raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(this package has no CPU fallback)" % path)
     lib = C.CDLL(path)
+    have = lib.stmpc_abi_version() if hasattr(lib, "stmpc_abi_version") else 0
+    if have != ABI_VERSION:
+        raise ImportError("%s implements ABI %d, this binding expects %d: rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)"
+                          % (path, have, ABI_VERSION))
     dp, ip, u8p, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_void_p
     pp = C.POINTER(Params)
     lib.stmpc_backend_info.restype = C.c_char_p
@@ -137,7 +143,11 @@ def load():
     lib.stmpc_solve_grid_no_jerk.argtypes = [vp, C.c_int, u8p, dp, C.c_int, dp, C.c_int, C.c_double, dp, dp]
     lib.stmpc_build_grid.argtypes = [vp, pp, dp, C.c_int, dp, dp, u8p, dp, dp, dp]
     lib.stmpc_predict_batch.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
-                                        dp, dp, dp, ip, dp]
+                                        dp, dp, dp, ip]
+    lib.stmpc_predict_batch_acc.argtypes = [vp, pp, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_double, C.c_double,
+                                            dp, dp, dp, ip, dp]
+    lib.stmpc_check_error.argtypes = [vp]
+    lib.stmpc_sim_status_device.argtypes = [vp, C.c_int, vp, vp]
     cp = C.POINTER(CombinedCfg)
     lib.stmpc_rollout_step_device.argtypes = [vp, pp, cp, C.c_int, C.c_int, C.c_int] + [vp] * 7 + [vp]
     lib.stmpc_combined_decide_device.argtypes = [vp, pp, cp, C.c_int, C.c_int] + [vp] * 12 + [vp]
@@ -375,11 +385,13 @@ class Context:
         vo = np.array(other_v, copy=True)
         cr = np.empty(N, dtype=np.int32)
         ao = np.zeros_like(other_x) if want_acc else None
-        self._chk(self._lib.stmpc_predict_batch(self._h, C.byref(params), int(mode), N, Kmax, _dptr(ego4), _iptr(k_count),
-                                                _dptr(other_x) if Kmax else None, _dptr(other_v) if Kmax else None,
-                                                _dptr(sel), float(dt), float(min_crash_distance), _dptr(eo),
-                                                _dptr(xo) if Kmax else None, _dptr(vo) if Kmax else None, _iptr(cr),
-                                                _dptr(ao) if (want_acc and Kmax) else None))
+        args = (self._h, C.byref(params), int(mode), N, Kmax, _dptr(ego4), _iptr(k_count), _dptr(other_x) if Kmax else None,
+                _dptr(other_v) if Kmax else None, _dptr(sel), float(dt), float(min_crash_distance), _dptr(eo),
+                _dptr(xo) if Kmax else None, _dptr(vo) if Kmax else None, _iptr(cr))
+        if want_acc:
+            self._chk(self._lib.stmpc_predict_batch_acc(*args, _dptr(ao) if Kmax else None))
+        else:
+            self._chk(self._lib.stmpc_predict_batch(*args))
         if want_acc:
             return eo, xo, vo, cr, ao
         return eo, xo, vo, cr
@@ -404,6 +416,14 @@ class Context:
 
     def sim_step(self, params, cfg, N, d_cmd_speed, stream=0):
         self._chk(self._lib.stmpc_sim_step_device(self._h, C.byref(params), C.byref(cfg), int(N), d_cmd_speed, stream))
+
+    def sim_status_device(self, N, d_status, stream=0):
+        """Environment status words into a device int32 array (asynchronous): 0 running, 1 arrived, 2 crashed, 3 out of time."""
+        self._chk(self._lib.stmpc_sim_status_device(self._h, int(N), d_status, stream))
+
+    def check_error(self):
+        """Synchronise and raise what kernels of earlier (asynchronous) calls on this context flagged; see ``stmpc_check_error``."""
+        self._chk(self._lib.stmpc_check_error(self._h))
 
     def sim_read(self, N):
         status, ticks = np.zeros(N, np.int32), np.zeros(N, np.int32)

@@ -62,7 +62,8 @@ def decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_las
                                cur_ox.data_ptr(), cur_ov.data_ptr(), first_action.data_ptr(),
                                d_last_choice_rl.data_ptr() if d_last_choice_rl is not None else 0,
                                takeover.data_ptr(), reason.data_ptr(), speed.data_ptr(), stream)
-    return {"takeover": takeover, "reason": reason, "speed": speed, "first_action": first_action}
+    return {"takeover": takeover, "reason": reason, "speed": speed, "first_action": first_action,
+            "cur_ego4": cur_ego4, "cur_ox": cur_ox, "cur_ov": cur_ov, "cur_oa": cur_oa}      # the last rolled-out state of every episode
 
 
 def decide_batch(states, get_control, ctx=None, last_choice_rl=None):
@@ -111,11 +112,12 @@ def decide_batch(states, get_control, ctx=None, last_choice_rl=None):
     hist = [list(st_["rollout_s"][j, :st_["hist_len"][j]]) for j in range(n)]
     # the probe state: the state after ST_TEST_ROLLOUTS steps, else the last rolled-out state (dqn.py:137-143)
     test_states = []
+    fin = [d[q].cpu().numpy() for q in ("cur_ego4", "cur_ox", "cur_ov", "cur_oa")]
     for j in range(n):
         if st_["have_test"][j]:
             test_states.append(_unpack(st_["test_ego4"], k, st_["test_ox"], st_["test_ov"], np.zeros_like(ox), j))
-        else:
-            test_states.append(None)
+        else:                                           # rollout ended before ST_TEST_ROLLOUTS: the last rolled-out state (dqn.py:142-143)
+            test_states.append(_unpack(fin[0], k, fin[1], fin[2], fin[3], j))
     st_speed = np.where(reason == REASON_ST_BETTER, speed, np.nan)
     return {"takeover": reason != REASON_RL, "reason": reason, "first_action": d["first_action"].cpu().numpy(),
             "selected_speed": st_["sel_speed"], "crash_predicted": st_["crash_pred"].astype(bool), "test_states": test_states,

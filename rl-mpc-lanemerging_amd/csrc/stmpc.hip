@@ -178,6 +178,7 @@ struct stmpc_ctx {
     double retry_mult[3] = {1.02, 1.08, 1.3};   // STMPC_RETRY="a,b,c"
     int retire_cus = 0, retire_at = 75;   // STMPC_RETIRE_CUS=k, STMPC_RETIRE_AT=percent of N: k compute units leave the first launch once fewer than that many tasks are left (see SolveArgs::cu_tab)
     DevBuf cu_tab;
+    DevBuf sticky;                 // [2] error flags that outlive a call: [0] solver internal error, [1] QP re-sampling refused a path (read and cleared by stmpc_check_error)
     hipStream_t main_masked = nullptr, aux_reserved = nullptr;
     hipEvent_t ev_join0 = nullptr, ev_join_r = nullptr;
 };
@@ -283,6 +284,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
         if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
     }
     if (!c->aux_stream) c->overlap = 0;          // no side stream: the tiers simply run one after the other
+    if (c->sticky.ensure(2 * sizeof(unsigned)) || hipMemset(c->sticky.p, 0, 2 * sizeof(unsigned)) != hipSuccess) { stmpc_destroy(c); return fail(STMPC_ENOMEM, "device allocation failed"); }
     if (const char *w = getenv("STMPC_RETRY")) { double x[3]; if (sscanf(w, "%lf,%lf,%lf", &x[0], &x[1], &x[2]) == 3 && x[0] > 1.0 && x[1] > 1.0 && x[2] > 1.0) for (int i = 0; i < 3; ++i) c->retry_mult[i] = x[i]; }
     if (const char *w = getenv("STMPC_RETIRE_CUS")) { int v = atoi(w); if (v >= 0 && v < 256) c->retire_cus = v; }
     if (const char *w = getenv("STMPC_RETIRE_AT")) { int v = atoi(w); if (v >= 1 && v <= 200) c->retire_at = v; }
@@ -313,7 +315,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
+    DevBuf *all[] = {&c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
@@ -411,9 +413,10 @@ int make_devp(const stmpc_params *p, DevP *d) {
 
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
-                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st) {
+                    CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st,
+                    unsigned *sticky = nullptr) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky);
 }
 
 }  // namespace
@@ -450,7 +453,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if ((rc = c->tab_win.ensure((size_t)N * H * Kalloc * 2 * sizeof(int)))) return rc;
     if ((rc = c->tab_nact.ensure((size_t)N * H * sizeof(int)))) return rc;
     if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
-    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
+    if (!c->counters.p) { if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc; HIPCHK(hipMemsetAsync(c->counters.p, 0, 64 * sizeof(unsigned), st)); }
     if ((rc = c->lists.ensure((size_t)STMPC_MAX_TIERS * N * sizeof(int)))) return rc;
     if ((rc = c->ubound.ensure((size_t)N * sizeof(u64)))) return rc;
     if ((rc = c->proxy.ensure((size_t)N * sizeof(unsigned)))) return rc;
@@ -505,6 +508,12 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const size_t bp0_per_episode = (size_t)N * H * tierW[0] * sizeof(u16);
     bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
                   bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
+    if (resume && c->bp_tier[0].cap < bp0_per_episode) {
+        // a growing request: only while it is at most a quarter of what the device has free right now (a process shared with torch / RCCL)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (bp0_per_episode + (size_t)N * (16 + (size_t)tierW[0] * 12) > (free_b + c->bp_tier[0].cap) / 4) resume = false;
+    }
     const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
     // reserved compute units (experiment, STMPC_CU_RESERVE): the first window's persistent grid covers the remaining units only
     const bool reserve_cfg = c->cu_reserve > 0 && prune_on && nt >= 2 && tierLds[0] && tierLds[1] && !c->two_phase;
@@ -549,9 +558,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if (heavy_first && (rc = c->prio_key.ensure((size_t)N))) return rc;
     unsigned char *prio_key = heavy_first ? c->prio_key.as<unsigned char>() : nullptr;
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -919,7 +928,31 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
 
 int stmpc_predict_batch(stmpc_ctx *c, const stmpc_params *p, int mode, int N, int Kmax, const double *ego4,
                         const int32_t *k, const double *ox, const double *ov, const double *sel, double dt,
-                        double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed, double *oa_out) {
+                        double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed) {
+    return stmpc_predict_batch_acc(c, p, mode, N, Kmax, ego4, k, ox, ov, sel, dt, mcd, ego4_out, ox_out, ov_out, crashed, nullptr);
+}
+
+int stmpc_abi_version(void) { return STMPC_ABI_VERSION; }
+
+int stmpc_check_error(stmpc_ctx *c) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned flags[2] = {0, 0}, cur = 0;
+    HIPCHK(hipMemcpy(flags, c->sticky.p, sizeof flags, hipMemcpyDeviceToHost));
+    if (c->counters.p) HIPCHK(hipMemcpy(&cur, (const unsigned *)c->counters.p + STMPC_CNT_ERR, sizeof cur, hipMemcpyDeviceToHost));
+    if (flags[0] || flags[1] || cur) {
+        HIPCHK(hipMemset(c->sticky.p, 0, sizeof flags));
+        if (cur) HIPCHK(hipMemset((unsigned *)c->counters.p + STMPC_CNT_ERR, 0, sizeof cur));
+    }
+    if (flags[0] || cur) return fail(STMPC_EINTERNAL, "solver error flag set on device (an episode of an earlier batch may not have been solved)");
+    if (flags[1]) return fail(STMPC_EINVAL, "finer_fit: a fine grid longer than STMPC_QP_NMAX samples is not supported (the commanded speed of that state is not valid)");
+    return STMPC_OK;
+}
+
+int stmpc_predict_batch_acc(stmpc_ctx *c, const stmpc_params *p, int mode, int N, int Kmax, const double *ego4,
+                            const int32_t *k, const double *ox, const double *ov, const double *sel, double dt,
+                            double mcd, double *ego4_out, double *ox_out, double *ov_out, int32_t *crashed, double *oa_out) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
     if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || (mode != 0 && mode != 1)) return fail(STMPC_EINVAL, "bad N/Kmax/mode");
     if (N == 0) return STMPC_OK;
@@ -1216,8 +1249,11 @@ int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmp
                                  const double *d_cur_ego4, const double *d_cur_ox, const double *d_cur_ov, const double *d_first_action,
                                  const int32_t *d_last_choice_rl, int32_t *d_takeover, int32_t *d_reason, double *d_speed, void *stream) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (!p || !g) return fail(STMPC_EINVAL, "NULL parameter struct");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N or Kmax out of range");
     if (N == 0) return STMPC_OK;
     if (!d_ego5_start || !d_k || !d_cur_ego4 || !d_first_action || !d_takeover || !d_reason || !d_speed) return fail(STMPC_EINVAL, "NULL device pointer");
+    if (Kmax > 0 && (!d_ox_start || !d_ov_start || !d_cur_ox || !d_cur_ov)) return fail(STMPC_EINVAL, "NULL device pointer (vehicles)");
     HIPCHK(hipSetDevice(c->device));
     CCfg cc;
     int rc = make_ccfg(p, g, &cc);
@@ -1237,14 +1273,12 @@ int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmp
     if ((rc = c->cc_speed.ensure((size_t)N * 8))) return rc;
     if ((rc = c->cc_fine.ensure((size_t)N * STMPC_QP_NMAX * 8))) return rc;
     if ((rc = c->cc_fine_len.ensure((size_t)N * 4))) return rc;
-    if ((rc = c->cc_err.ensure(4))) return rc;
     CCState st = cc_state(c);
     const int blocks = (N + 63) / 64;
-    HIPCHK(hipMemsetAsync(c->cc_err.p, 0, 4, st_));
     HIPCHK(hipMemsetAsync(c->cc_pcrash.p, 0, (size_t)N * 4, st_));
     // 1. feasibility probe of the rolled-out state (st.test_guaranteed_crash_from_state, dqn.py:152): one batched solve
     if (cc.test_rollout_state) {
-        hipLaunchKernelGGL(k_cc_probe_state, dim3(blocks), dim3(64), 0, st_, N, Kalloc, d_cur_ego4, d_cur_ox, d_cur_ov, st, c->cc_probe_ego.as<double>(),
+        hipLaunchKernelGGL(k_cc_probe_state, dim3(blocks), dim3(64), 0, st_, N, Kalloc, Kmax, d_k, d_cur_ego4, d_cur_ox, d_cur_ov, st, c->cc_probe_ego.as<double>(),
                            c->cc_probe_ox.as<double>(), c->cc_probe_ov.as<double>());
         if ((rc = stmpc_solve_batch_device(c, p, N, Kmax, c->cc_probe_ego.as<double>(), d_k, c->cc_probe_ox.as<double>(), c->cc_probe_ov.as<double>(),
                                            c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(), c->cc_cost.as<double>(), nullptr, c->cc_pcrash.as<int32_t>(), stream))) return rc;
@@ -1256,7 +1290,7 @@ int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmp
     // 3. the decision
     hipLaunchKernelGGL(k_cc_decide, dim3(blocks), dim3(64), 0, st_, cc, N, d_ego5_start, d_first_action, d_last_choice_rl, st, (const int *)c->cc_pcrash.as<int>(),
                        (const double *)c->cc_speed.as<double>(), (const double *)c->cc_fine.as<double>(), (const int *)c->cc_fine_len.as<int>(), STMPC_QP_NMAX,
-                       d_takeover, d_reason, d_speed, c->cc_err.as<unsigned>());
+                       d_takeover, d_reason, d_speed, c->sticky.as<unsigned>() + 1);
     HIPCHK(hipGetLastError());
     return STMPC_OK;
 }
@@ -1282,12 +1316,7 @@ int stmpc_combined_read_state(stmpc_ctx *c, int N, int32_t *live, int32_t *hist_
     if (st_speed && c->cc_speed.p) HIPCHK(hipMemcpy(st_speed, c->cc_speed.p, (size_t)N * 8, hipMemcpyDeviceToHost));
     if (fine && c->cc_fine.p) HIPCHK(hipMemcpy(fine, c->cc_fine.p, (size_t)N * STMPC_QP_NMAX * 8, hipMemcpyDeviceToHost));
     if (fine_len && c->cc_fine_len.p) HIPCHK(hipMemcpy(fine_len, c->cc_fine_len.p, (size_t)N * 4, hipMemcpyDeviceToHost));
-    if (c->cc_err.p) {
-        unsigned e = 0;
-        HIPCHK(hipMemcpy(&e, c->cc_err.p, 4, hipMemcpyDeviceToHost));
-        if (e) return fail(STMPC_EINVAL, "finer_fit: a fine grid longer than STMPC_QP_NMAX samples is not supported");
-    }
-    return STMPC_OK;
+    return stmpc_check_error(c);         // (device already synchronised: just the flags)
 }
 
 int stmpc_solve_grid_no_jerk(stmpc_ctx *c, int variant, const uint8_t *obstacles, const double *s_values, int S, const double *t_values,
@@ -1407,6 +1436,14 @@ int stmpc_sim_step_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_sim_c
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(sim::k_sim_step, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, dp, sc, N, sim_state(c), d_cmd_speed, p->crash_min_s);
     HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_sim_status_device(stmpc_ctx *c, int N, int32_t *d_status, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (N != c->sim_N || !d_status) return fail(STMPC_EINVAL, "N does not match stmpc_sim_init_device, or NULL pointer");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(d_status, c->sim_status.p, (size_t)N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return STMPC_OK;
 }
 

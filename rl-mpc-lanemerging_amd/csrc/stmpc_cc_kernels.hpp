@@ -96,17 +96,22 @@ __global__ void __launch_bounds__(64) k_rollout_step(DevP p, CCfg c, int N, int 
 
 // Probe state of the episodes whose rollout ended before step ST_TEST_ROLLOUTS (dqn.py:142-143), as the 5-column state
 // the solver takes (start_s of the probe state from the device map of control.get_ego_s).
-__global__ void __launch_bounds__(64) k_cc_probe_state(int N, int Kmax, const double *__restrict__ cur_ego4, const double *__restrict__ cur_ox,
+__global__ void __launch_bounds__(64) k_cc_probe_state(int N, int Kmax /* row stride */, int Kcopy /* vehicles per row the caller's arrays hold (0: none, pointers may be null) */,
+                                                       const int *__restrict__ k_count, const double *__restrict__ cur_ego4, const double *__restrict__ cur_ox,
                                                        const double *__restrict__ cur_ov, CCState st, double *probe_ego5, double *probe_ox, double *probe_ov) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const bool ht = st.have_test[e] != 0;
     const double *src4 = ht ? st.test_ego4 + (size_t)e * 4 : cur_ego4 + (size_t)e * 4;
-    const double *sx = ht ? st.test_ox + (size_t)e * Kmax : cur_ox + (size_t)e * Kmax;
-    const double *sv = ht ? st.test_ov + (size_t)e * Kmax : cur_ov + (size_t)e * Kmax;
     for (int q = 0; q < 4; ++q) probe_ego5[(size_t)e * 5 + q] = src4[q];
     probe_ego5[(size_t)e * 5 + 4] = dev_ego_s(src4[0], src4[1]);
-    for (int i = 0; i < Kmax; ++i) { probe_ox[(size_t)e * Kmax + i] = sx[i]; probe_ov[(size_t)e * Kmax + i] = sv[i]; }
+    int k = k_count[e];
+    k = k < 0 ? 0 : (k > Kcopy ? Kcopy : k);                                    // only the episode's own vehicles are copied; the rest of the row is zero
+    for (int i = 0; i < Kmax; ++i) {
+        double x = 0.0, v = 0.0;
+        if (i < k) { x = ht ? st.test_ox[(size_t)e * Kmax + i] : cur_ox[(size_t)e * Kmax + i]; v = ht ? st.test_ov[(size_t)e * Kmax + i] : cur_ov[(size_t)e * Kmax + i]; }
+        probe_ox[(size_t)e * Kmax + i] = x; probe_ov[(size_t)e * Kmax + i] = v;
+    }
 }
 
 // The decision, dqn.py:144-200.  probe_crash = st.test_guaranteed_crash_from_state(test_state); st_speed / fine / fine_len =
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(64) k_cc_decide(CCfg c, int N, const double *_
     else if (c.test_rollout_state && probe_crash[e]) reason = CC_ROLLOUT;
     else if (c.strictly_better) {
         const int m = fine_len[e];
-        if (m < 0) atomicExch(err, 1u);                                         // fine grid longer than the QP kernel supports
+        if (m < 0) atomicOr(err, 1u);                                           // fine grid longer than the QP kernel supports
         else if (m > 1) {                                                      // dqn.py:167-169: a single point = nothing to compare
             const int hl = st.hist_len[e];
             const int ml = m < hl ? m : hl;
@@ -140,7 +145,10 @@ __global__ void __launch_bounds__(64) k_cc_decide(CCfg c, int N, const double *_
             if (choose) { reason = CC_ST_BETTER; speed = (fs[1] - fs[0]) / c.tick; }        // dqn.py:180-181,192-193
         }
     }
-    if (reason == CC_CRASH || reason == CC_SPEED || reason == CC_ROLLOUT) speed = st_speed[e];   // st.do_st_control(start_state)
+    if (reason == CC_CRASH || reason == CC_SPEED || reason == CC_ROLLOUT) {
+        speed = st_speed[e];                                                    // st.do_st_control(start_state)
+        if (fine_len[e] < 0) atomicOr(err, 1u);                                 // ... which could not re-sample its path: the command is not the reference's
+    }
     takeover[e] = reason != CC_RL;
     reason_out[e] = reason;
     speed_out[e] = speed;

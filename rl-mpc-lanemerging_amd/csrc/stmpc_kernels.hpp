@@ -227,8 +227,11 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */,
                                                 unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */,
                                                 int *resume_t /* [N] or null: zeroed here */,
-                                                unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */) {
+                                                unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */,
+                                                unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
+    // the previous solve's error flag is latched before the counters are reused (same wavefront: the read precedes lane 63's store)
+    if (e == 0 && sticky && counters[63 /* STMPC_CNT_ERR */]) atomicOr(&sticky[0], 1u);
     if (e < 64) counters[e] = 0u;
     if (e >= N) return;
     if (ubound) ubound[e] = 0ull;

@@ -66,6 +66,7 @@ def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max
     takeovers = torch.zeros(n, dtype=torch.float64, device=dev)
     controlled = torch.zeros(n, dtype=torch.float64, device=dev)
     last_rl = torch.ones(n, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
     ctx.sim_init(cfg, n)
     for tick in range(cfg.max_ticks + 1):
         ctx.sim_view(cfg, n, kmax, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr())
@@ -76,16 +77,24 @@ def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max
         else:
             d = combined.decide_batch_device(ctx, params, ccfg, d_ego5, d_k, d_ox, d_ov, policy, last_rl)
             cmd = d["speed"]
-            takeovers += d["takeover"].to(torch.float64)
-            controlled += 1.0
+            # per-episode takeover share (the reference's stats count the ticks of the episode itself): finished environments keep
+            # returning their final state from sim_view, their repeated decisions must not be counted
+            ctx.sim_status_device(n, d_status.data_ptr())
+            running = (d_status == 0).to(torch.float64)
+            takeovers += d["takeover"].to(torch.float64) * running
+            controlled += running
             last_rl = (d["takeover"] == 0).to(torch.int32)
         ctx.sim_step(params, cfg, n, cmd.data_ptr())
         if tick % check_every == check_every - 1:
             status, _, _, _ = ctx.sim_read(n)
+            ctx.check_error()          # (an asynchronous solver / QP error of the ticks since the last check)
             if (status != 0).all():
                 break
     status, ticks, acc, _ = ctx.sim_read(n)
+    ctx.check_error()
     samples = np.maximum(acc[:, 4], 1.0)
+    # mean |jerk| as the reference reports it: its jerk history holds a 0 for the first tick (control.py:284-287) and the mean is taken
+    # over all ticks (stats.py:60) -- n samples, not n - 1 jerk terms
     out = {"crashed": (status == 2).astype(np.float64), "merged": (status == 1).astype(np.float64), "timed_out": (status == 3).astype(np.float64),
            "mean_speed": acc[:, 0] / samples, "max_speed": acc[:, 1], "mean_abs_jerk": acc[:, 2] / samples,
            "closest_distance": np.where(acc[:, 7] > 0, acc[:, 5], np.nan), "mean_closest_distance": np.where(acc[:, 7] > 0, acc[:, 6] / np.maximum(acc[:, 7], 1.0), np.nan),
