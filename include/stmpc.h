@@ -319,9 +319,11 @@ int stmpc_combined_read_state(stmpc_ctx *ctx, int N, int32_t *live, int32_t *his
 
 /*
  * Batched SUMO-free merge episodes: stands in for control.run_episode / control.step (control.py:207-340) so that whole
- * episodes can be run for N environments in lock-step on the device.  The world is the planner's own model (ego motion
- * prediction.py:46-59, follower rule prediction.py:75-97, vehicles entering the highway as control.py:215-226 adds them), NOT
- * SUMO's: episode statistics compare with the reference's reports as distributions only.
+ * episodes can be run for N environments in lock-step on the device.  The world restates what the reference configures SUMO to do
+ * (the "simple traffic distribution", config.py:39): highway vehicles of vType "normal" follow SUMO's Krauss model (Euler form,
+ * sigma 0) behind the vehicle ahead and behind the ego once that is on the junction, they enter as control.py:215-226 adds them,
+ * the ego obeys its acceleration limits only (speed mode 22, control.py:43) and moves along the straight lines the planner assumes
+ * (prediction.py:46-59).  It is not SUMO: episode statistics compare with the reference's reports as distributions only.
  *   stmpc_sim_init_device   traffic in its stationary state, ego at the ramp start with control.get_ego_start_speed's draw
  *   stmpc_sim_view_device   planner inputs of every environment (the layout stmpc_solve_batch_device takes; vehicles within the
  *                           sensor radius, front to back; other_a may be NULL)
@@ -339,7 +341,13 @@ typedef struct stmpc_sim_cfg {
     double arrive_x;                 /* arrivalPos 50 on highwayahead = x 51.5 (control.py:42) */
     double sensor_radius;            /* Settings.SENSOR_RADIUS */
     double start_speed, start_speed_std, min_start_speed, max_start_speed;   /* control.py:198-204 */
+    /* the highway vehicles' SUMO vType (merge_impossible.rou.xml:3 "normal": Krauss, accel 4.5, decel 6.0, minGap 1, tau 0.5, length 5; SUMO's
+     * defaults: emergencyDecel 9, width 1.8); speed_dev = deviation of the per-vehicle speed factor (0 in the simple distribution) */
+    double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
     int32_t vary_traffic_start_times, randomize_start_speed, max_ticks;
+    int32_t yield_overlap;           /* a highway vehicle whose front is behind the ego's front but ahead of its rear (the two overlap along the converging lanes):
+                                        1 = it treats the ego as its leader at once (SUMO's link leader with a negative gap), 0 = only where the lanes are less than
+                                        a vehicle width apart */
     uint64_t seed;
 } stmpc_sim_cfg;
 int stmpc_sim_init_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, void *stream);

@@ -70,8 +70,10 @@ class SimCfg(C.Structure):
     _fields_ = [("tick_length", C.c_double), ("other_car_speed", C.c_double), ("base_traffic_interval", C.c_double), ("spawn_x", C.c_double),
                 ("despawn_x", C.c_double), ("ego_start_x", C.c_double), ("ego_start_y", C.c_double), ("arrive_x", C.c_double),
                 ("sensor_radius", C.c_double), ("start_speed", C.c_double), ("start_speed_std", C.c_double), ("min_start_speed", C.c_double),
-                ("max_start_speed", C.c_double), ("vary_traffic_start_times", C.c_int32), ("randomize_start_speed", C.c_int32),
-                ("max_ticks", C.c_int32), ("seed", C.c_uint64)]
+                ("max_start_speed", C.c_double), ("veh_accel", C.c_double), ("veh_decel", C.c_double), ("veh_min_gap", C.c_double), ("veh_tau", C.c_double),
+                ("veh_emergency_decel", C.c_double), ("veh_length", C.c_double), ("veh_width", C.c_double), ("speed_dev", C.c_double),
+                ("vary_traffic_start_times", C.c_int32), ("randomize_start_speed", C.c_int32),
+                ("max_ticks", C.c_int32), ("yield_overlap", C.c_int32), ("seed", C.c_uint64)]
 
 
 class ProfileTotals(C.Structure):

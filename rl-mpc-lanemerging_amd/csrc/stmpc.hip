@@ -1376,7 +1376,11 @@ int make_simcfg(const stmpc_sim_cfg *g, sim::Cfg *c) {
     c->spawn_x = g->spawn_x; c->despawn_x = g->despawn_x; c->ego_start_x = g->ego_start_x; c->ego_start_y = g->ego_start_y; c->arrive_x = g->arrive_x;
     c->sensor_radius = g->sensor_radius; c->start_speed = g->start_speed; c->start_speed_std = g->start_speed_std;
     c->min_start_speed = g->min_start_speed; c->max_start_speed = g->max_start_speed;
-    c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->seed = g->seed;
+    if (!(g->veh_accel > 0) || !(g->veh_decel > 0) || !(g->veh_tau >= 0) || !(g->veh_length > 0) || !(g->veh_emergency_decel >= g->veh_decel) || g->veh_min_gap < 0 || g->speed_dev < 0)
+        return fail(STMPC_EINVAL, "vehicle type parameters (accel, decel, tau, length, emergency decel, minGap, speed_dev) out of range");
+    c->veh_accel = g->veh_accel; c->veh_decel = g->veh_decel; c->veh_min_gap = g->veh_min_gap; c->veh_tau = g->veh_tau; c->veh_emergency_decel = g->veh_emergency_decel;
+    c->veh_length = g->veh_length; c->veh_width = g->veh_width; c->speed_dev = g->speed_dev;
+    c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->yield_overlap = g->yield_overlap; c->seed = g->seed;
     return STMPC_OK;
 }
 sim::State sim_state(stmpc_ctx *c) {

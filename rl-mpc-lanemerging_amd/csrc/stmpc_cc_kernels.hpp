@@ -156,23 +156,29 @@ __global__ void __launch_bounds__(64) k_cc_decide(CCfg c, int N, const double *_
 
 // ------------------------------------------------------------------------------------------------------------------
 // SUMO-free batched merge episodes (stands in for control.run_episode / control.step,
-// control.py:215-340).  The world IS the planner's own model: the ego moves as prediction.py:46-59 says, the highway
-// vehicles follow prediction.py:75-97 (constant speed, braking behind a slower leader within 30 m, reacting to the ego once
-// it has merged), vehicles enter the highway as control.step adds them (control.py:215-226) and leave at its end.  Nothing
-// here reproduces SUMO's Krauss model, so episode statistics are comparable with the reference's reports only as
-// distributions -- and are labelled so.  One thread per environment; vehicles live in [N][KS] arrays, front to back.
+// control.py:215-340).  The traffic is the reference's "simple traffic distribution" (config.py:39, sumo.py:43-58): vehicles of
+// SUMO's vType "normal" of merge_impossible.rou.xml:3 -- car-following model Krauss, accel 4.5, decel 6.0, minGap 1, tau 0.5,
+// sigma 0, speedFactor 1 / speedDev 0, maxSpeed = OTHER_CAR_SPEED -- added at the start of the highway every
+// BASE_TRAFFIC_INTERVAL (+ U(0,1)) seconds (control.py:215-226), and the ego under speed mode 22 (control.py:43: it obeys its
+// acceleration limits and nothing else).  The Krauss follow speed is SUMO's Euler form (MSCFModel::maximumSafeStopSpeedEuler /
+// maximumSafeFollowSpeed), a highway vehicle regards as its leader the vehicle ahead and, once the ego is on the junction's internal
+// lane or beyond, the ego if that is ahead of it (SUMO's link-leader rule for merging internal lanes of equal length); bodies collide
+// when they overlap along the lane while the converging lanes are less than a vehicle width apart.  This is a restatement of
+// SUMO's documented models, not SUMO: episode statistics compare with the reference's reports as DISTRIBUTIONS -- and are labelled so.
+// One thread per environment; vehicles live in [N][KS] arrays, front to back.
 namespace sim {
 constexpr int KS = 64;             // vehicle slots per environment
 struct Cfg {
     double tick, other_speed, base_interval, spawn_x, despawn_x, ego_start_x, ego_start_y, arrive_x, sensor_radius;
     double start_speed, start_speed_std, min_start_speed, max_start_speed;
-    int vary_interval, randomize_start_speed, max_ticks;
+    double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
+    int vary_interval, randomize_start_speed, max_ticks, yield_overlap;
     unsigned long long seed;
 };
 struct State {                     // device arrays
     double *ego4;                  // [N][4] x, y, v, a
     int *nveh;                     // [N]
-    double *vx, *vv, *va, *vc;     // [N][KS] position, speed, acceleration, cruise speed of each vehicle
+    double *vx, *vv, *va, *vc;     // [N][KS] position (front bumper, as traci reports it), speed, acceleration, desired speed of each vehicle
     double *delay;                 // [N] time to the next highway vehicle
     int *status;                   // [N] 0 running, 1 arrived ("merged"), 2 crashed, 3 out of time
     int *ticks;                    // [N] controlled ticks so far
@@ -184,27 +190,54 @@ __device__ __forceinline__ double uniform01(unsigned long long seed, int env, un
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;      // splitmix64
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
-// SUMO's vType "normal" (merge.rou.xml:28-29, maxSpeed set to OTHER_CAR_SPEED by sumo.py:58): each vehicle cruises at
-// OTHER_CAR_SPEED * speedFactor, speedFactor ~ normc(1.0, 0.1) clipped to [0.2, 2]; a vehicle is inserted only when the one
-// ahead leaves the IDM desired gap minGap + v * tau + length = 2.5 + v + 5 free (SUMO postpones unsafe insertions).
+// desired speed of a vehicle: OTHER_CAR_SPEED * speedFactor, speedFactor ~ normc(1, speed_dev) clipped to [0.2, 2] (0 = exactly 1, the simple distribution)
 __device__ __forceinline__ double cruise_speed(const Cfg &c, int env, unsigned &ctr) {
+    if (!(c.speed_dev > 0.0)) return c.other_speed;
     const double u1 = uniform01(c.seed, env, ctr), u2 = uniform01(c.seed, env, ctr);
-    double f = 1.0 + 0.1 * sqrt(-2.0 * log(u1 > 1e-300 ? u1 : 1e-300)) * cos(6.283185307179586 * u2);
+    double f = 1.0 + c.speed_dev * sqrt(-2.0 * log(u1 > 1e-300 ? u1 : 1e-300)) * cos(6.283185307179586 * u2);
     f = f < 0.2 ? 0.2 : (f > 2.0 ? 2.0 : f);
     return c.other_speed * f;
 }
+// distance covered while braking from `speed` with `decel` in whole steps (MSCFModel::brakeGapEuler, headway 0)
+__device__ __forceinline__ double brake_gap(double speed, double decel, double ts) {
+    const double red = decel * ts;
+    const int steps = (int)(speed / red);
+    return ts * ((double)steps * speed - red * (double)steps * (double)(steps + 1) / 2.0);
+}
+// largest speed from which the vehicle can still stop within `gap` when it brakes with `decel` after its reaction time (MSCFModel::maximumSafeStopSpeedEuler)
+__device__ __forceinline__ double safe_stop_speed(double gap, double decel, double tau, double ts) {
+    const double g = gap - 0.001;
+    if (g < 0.0) return 0.0;
+    const double b = decel * ts, t = tau, s_ = ts;
+    const double n = floor(0.5 - ((t + (sqrt((s_ * s_) + (4.0 * ((s_ * (2.0 * g / b - t)) + (t * t)))) * -0.5)) / s_));
+    const double h = 0.5 * n * (n - 1.0) * b * s_ + n * b * t;
+    const double r = (g - h) / (n * s_ + t);
+    const double x = n * b + r;
+    return x > 0.0 ? x : 0.0;
+}
+// Krauss: the speed that stays safe behind a leader `gap` ahead (net of minGap) that may brake with the same deceleration (MSCFModel::maximumSafeFollowSpeed)
+__device__ __forceinline__ double krauss_follow(const Cfg &c, double gap, double lead_speed) {
+    return safe_stop_speed(gap + brake_gap(lead_speed, c.veh_decel, c.tick), c.veh_decel, c.veh_tau, c.tick);
+}
+// position of the ego along the highway lane once it is on the junction's internal lane: both internal lanes start at x = -50.6, are 52.2 m long and
+// end at x = 1.5, and the ego moves on the planner's straight line (prediction.py:46-59), whose x extent differs from its length by 0.3 %: the
+// x coordinate itself, which is also what the planner compares with the vehicles' (prediction.py:78)
+__device__ __forceinline__ double ego_lane_pos(double x, double /*y*/) { return x; }
 __global__ void __launch_bounds__(64) k_sim_init(Cfg c, int N, State s) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     unsigned ctr = 0;
-    // highway traffic in its stationary state (what the reference gets from 20 s of warm-up ticks, control.py:255-256)
+    // highway traffic in its stationary state (what the reference gets from its warm-up ticks, control.py:255-258): every vehicle at its desired
+    // speed, spaced by the insertion intervals; an insertion that is not yet safe is postponed, as SUMO does
     int n = 0;
-    double x = c.despawn_x - c.other_speed * uniform01(c.seed, e, ctr) * (c.base_interval + (c.vary_interval ? 1.0 : 0.0));
-    const double min_gap = 2.5 + c.other_speed + 5.0;
+    const double head0 = c.base_interval + (c.vary_interval ? uniform01(c.seed, e, ctr) : 0.0);
+    double x = c.despawn_x - c.other_speed * uniform01(c.seed, e, ctr) * head0;
+    const double min_space = c.veh_length + c.veh_min_gap + c.other_speed * c.veh_tau;
     while (x > c.spawn_x && n < KS) {
-        s.vx[(size_t)e * KS + n] = x; s.vv[(size_t)e * KS + n] = c.other_speed; s.va[(size_t)e * KS + n] = 0.0; s.vc[(size_t)e * KS + n] = cruise_speed(c, e, ctr); ++n;
+        const double vc_ = cruise_speed(c, e, ctr);
+        s.vx[(size_t)e * KS + n] = x; s.vv[(size_t)e * KS + n] = vc_ < c.other_speed ? vc_ : c.other_speed; s.va[(size_t)e * KS + n] = 0.0; s.vc[(size_t)e * KS + n] = vc_; ++n;
         const double step = c.other_speed * (c.base_interval + (c.vary_interval ? uniform01(c.seed, e, ctr) : 0.0));
-        x -= step > min_gap ? step : min_gap;
+        x -= step > min_space ? step : min_space;
     }
     s.nveh[e] = n;
     s.delay[e] = (x - c.spawn_x) / (c.other_speed > 0 ? -c.other_speed : -1.0);      // (x < spawn_x here: the next vehicle enters after that time)
@@ -219,7 +252,8 @@ __global__ void __launch_bounds__(64) k_sim_init(Cfg c, int N, State s) {
     for (int q = 0; q < 8; ++q) s.acc[(size_t)e * 8 + q] = 0.0;
     s.acc[(size_t)e * 8 + 5] = 1e300;
 }
-// The planner's view of each environment: the vehicles within the sensor radius, front to back, and the ego with its s coordinate.
+// The planner's view of each environment (HighwayState.from_sumo, prediction.py:112-142): the vehicles within the sensor radius of the ego (plane
+// distance; the highway lane runs at y = -1.6), front to back, and the ego with its s coordinate.
 __global__ void __launch_bounds__(64) k_sim_view(Cfg c, int N, int Kmax, State s, double *ego5, int *k_count, double *ox, double *ov, double *oa) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
@@ -230,7 +264,8 @@ __global__ void __launch_bounds__(64) k_sim_view(Cfg c, int N, int Kmax, State s
     const int n = s.nveh[e];
     for (int i = 0; i < n && k < Kmax; ++i) {
         const double x = s.vx[(size_t)e * KS + i];
-        if (fabs(x - ex) <= c.sensor_radius) { ox[(size_t)e * Kmax + k] = x; ov[(size_t)e * Kmax + k] = s.vv[(size_t)e * KS + i]; if (oa) oa[(size_t)e * Kmax + k] = s.va[(size_t)e * KS + i]; ++k; }
+        const double dx = x - ex, dy = -1.6 - ey;
+        if (sqrt(dx * dx + dy * dy) < c.sensor_radius) { ox[(size_t)e * Kmax + k] = x; ov[(size_t)e * Kmax + k] = s.vv[(size_t)e * KS + i]; if (oa) oa[(size_t)e * Kmax + k] = s.va[(size_t)e * KS + i]; ++k; }
     }
     for (int i = k; i < Kmax; ++i) { ox[(size_t)e * Kmax + i] = 0.0; ov[(size_t)e * Kmax + i] = 0.0; if (oa) oa[(size_t)e * Kmax + i] = 0.0; }
     k_count[e] = k;
@@ -240,15 +275,15 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N || s.status[e] != 0) return;
     const double dt = c.tick;
-    double cx = s.ego4[e * 4 + 0], cy = s.ego4[e * 4 + 1];
+    const double cx = s.ego4[e * 4 + 0], cy = s.ego4[e * 4 + 1];
     const double v_prev = s.ego4[e * 4 + 2];
     double sel = cmd_speed[e];
     if (!(sel == sel)) sel = v_prev;                                              // (a NaN command keeps the speed)
-    // the vehicle cannot change its speed faster than its acceleration limits (SUMO vType accel 4.5 / decel 6.0, merge.rou.xml:2)
+    // speed mode 22: the ego obeys its vType's acceleration limits (accel 4.5 / decel 6.0, merge_impossible.rou.xml:2) and its lane's speed limit only
     const double hi = v_prev + p.a_max * dt, lo = v_prev + p.a_min * dt;
     sel = sel > hi ? hi : (sel < lo ? lo : sel);
     sel = sel < 0 ? 0 : (sel > p.v_max ? p.v_max : sel);
-    // ego motion, prediction.py:46-59
+    // ego motion along its route (the straight lines the planner assumes, prediction.py:46-59)
     double px, py;
     if (cx < 1.5) {
         double d0 = 1.5 - cx, d1 = -1.5 - cy;
@@ -259,30 +294,45 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     } else { py = cy; px = cx + sel * dt; }
     const double acc_ego = (sel - v_prev) / dt;
     const double es = dev_ego_s(px, py);
-    const bool can_crash = es > p.crash_thr, merged = es > p.react_thr;
-    // highway vehicles, prediction.py:75-97
+    // Highway vehicles (Krauss, front to back).  Every vehicle plans on the positions at the START of the step, as SUMO's planMovements does.
+    const bool ego_on_lane = cx >= -50.58;                                       // on the junction's internal lane or beyond: a leader for those behind it
+    const double ego_pos0 = ego_lane_pos(cx, cy);
     const int n = s.nveh[e];
-    double last_x = __builtin_inf(), last_speed = 0.0;
-    bool enc = false, crashed = false;
-    double gap = 100.0;
+    double lead_x = __builtin_inf(), lead_v = 0.0;                               // the vehicle ahead at the start of the step
+    bool crashed = false;
+    double gap_ahead = 100.0, gap_behind = 100.0;                                // distances to the nearest vehicles in front of / behind the ego (control.py:289-303)
+    const double ego_pos1 = ego_lane_pos(px, py);
+    // lateral distance of the converging lanes at the ego's position: bodies can touch only where it is below a vehicle width
+    const double lat = px < 1.5 ? 3.31 * (1.5 - px) / 52.08 : 0.0;
+    const double lat0 = cx < 1.5 ? 3.31 * (1.5 - cx) / 52.08 : 0.0;              // (the same at the start of the step)
     for (int i = 0; i < n; ++i) {
         const double ox_ = s.vx[(size_t)e * KS + i], ov_ = s.vv[(size_t)e * KS + i];
-        if (ox_ < px && !enc) { enc = true; if (merged) { last_x = px; last_speed = sel; } }
-        const double sd = last_speed - ov_, xd = last_x - ox_;
-        double a_ = 0.0, nv = ov_;
-        if (sd < 0 && xd < p.follow_gap) { a_ = sd > p.max_pred_decel ? sd : p.max_pred_decel; nv = ov_ + a_ * dt; }
-        else {                                                                    // free road: towards the vehicle's own cruise speed
-            const double vc_ = s.vc[(size_t)e * KS + i];
-            if (ov_ < vc_) { a_ = (vc_ - ov_) / dt; a_ = a_ > 2.6 ? 2.6 : a_; nv = ov_ + a_ * dt; }
-            else if (ov_ > vc_) { a_ = (vc_ - ov_) / dt; a_ = a_ < -2.0 ? -2.0 : a_; nv = ov_ + a_ * dt; }
+        double vnext = ov_ + c.veh_accel * dt;                                    // maxNextSpeed
+        const double vdes = s.vc[(size_t)e * KS + i];
+        vnext = vnext < vdes ? vnext : vdes;
+        if (lead_x < __builtin_inf()) {
+            const double vs = krauss_follow(c, lead_x - c.veh_length - ox_ - c.veh_min_gap, lead_v);
+            vnext = vs < vnext ? vs : vnext;
         }
-        const double nx = ox_ + nv * dt;
-        last_x = nx; last_speed = nv;
-        s.vx[(size_t)e * KS + i] = nx; s.vv[(size_t)e * KS + i] = nv; s.va[(size_t)e * KS + i] = a_;
-        const double d = fabs(nx - px);
-        if (d < p.car_length && can_crash) crashed = true;
-        gap = d < gap ? d : gap;
+        // the ego is a leader too (it may be closer than the vehicle ahead) once its rear is ahead of this vehicle's front -- or, if the two
+        // overlap along the lane, once the converging lanes are less than a vehicle width apart there (SUMO's sublane junction model: a foe
+        // that is laterally clear is beside the vehicle, not in front of it)
+        if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
+            const double vs = krauss_follow(c, ego_pos0 - c.veh_length - ox_ - c.veh_min_gap, v_prev);
+            vnext = vs < vnext ? vs : vnext;
+        }
+        const double vmin = ov_ - c.veh_emergency_decel * dt;                     // (a vehicle never brakes harder than its emergency deceleration)
+        vnext = vnext < vmin ? vmin : vnext;
+        vnext = vnext < 0.0 ? 0.0 : vnext;
+        const double nx = ox_ + vnext * dt;                                       // Euler update: the new speed for the whole step
+        lead_x = ox_; lead_v = ov_;
+        s.vx[(size_t)e * KS + i] = nx; s.vv[(size_t)e * KS + i] = vnext; s.va[(size_t)e * KS + i] = (vnext - ov_) / dt;
+        // collision: the bodies [x - length, x] overlap along the lane while the lanes are less than a vehicle width apart
+        if (px >= -50.58 && lat < c.veh_width && fabs(nx - ego_pos1) < c.veh_length) crashed = true;
+        const double d = fabs(nx - px);                                           // (the reference's closest-vehicle metric uses raw x differences)
+        if (nx >= px) gap_ahead = d < gap_ahead ? d : gap_ahead; else gap_behind = d < gap_behind ? d : gap_behind;
     }
+    const double gap = gap_ahead < gap_behind ? gap_ahead : gap_behind;
     // vehicles leaving at the end of the highway (front of the list) and entering at its start, control.py:215-226
     int nn = n, drop = 0;
     while (drop < nn && s.vx[(size_t)e * KS + drop] > c.despawn_x) ++drop;
@@ -290,16 +340,19 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     double delay = s.delay[e];
     unsigned ctr = s.rng[e];
     if (delay <= 0) {
-        const bool room = nn == 0 || s.vx[(size_t)e * KS + nn - 1] - c.spawn_x >= 2.5 + c.other_speed + 5.0;       // SUMO postpones an unsafe insertion
-        if (room && nn < KS) {
-            s.vx[(size_t)e * KS + nn] = c.spawn_x; s.vv[(size_t)e * KS + nn] = c.other_speed; s.va[(size_t)e * KS + nn] = 0.0; s.vc[(size_t)e * KS + nn] = cruise_speed(c, e, ctr); ++nn;
+        // SUMO inserts with departSpeed = OTHER_CAR_SPEED when that speed is safe behind the last vehicle, else postpones the insertion
+        bool room = nn < KS;
+        if (room && nn > 0) room = krauss_follow(c, s.vx[(size_t)e * KS + nn - 1] - c.veh_length - c.spawn_x - c.veh_min_gap, s.vv[(size_t)e * KS + nn - 1]) >= c.other_speed;
+        if (room) {
+            const double vc_ = cruise_speed(c, e, ctr);
+            s.vx[(size_t)e * KS + nn] = c.spawn_x; s.vv[(size_t)e * KS + nn] = vc_ < c.other_speed ? vc_ : c.other_speed; s.va[(size_t)e * KS + nn] = 0.0; s.vc[(size_t)e * KS + nn] = vc_; ++nn;
             delay = (c.vary_interval ? uniform01(c.seed, e, ctr) : 0.0) + c.base_interval;
         }
     }
     delay -= dt;
     s.delay[e] = delay; s.rng[e] = ctr; s.nveh[e] = nn;
     s.ego4[e * 4 + 0] = px; s.ego4[e * 4 + 1] = py; s.ego4[e * 4 + 2] = sel; s.ego4[e * 4 + 3] = acc_ego;
-    // episode statistics, control.py:276-283 / stats.py:43-75
+    // episode statistics, control.py:276-305 / stats.py:43-75
     double *a = s.acc + (size_t)e * 8;
     const int tk = s.ticks[e];
     a[0] += sel; a[1] = sel > a[1] ? sel : a[1];

@@ -2,11 +2,14 @@
 ``control.evaluate_control`` (control.py:207-395) and of the per-episode columns of ``stats.StatsAggregator``
 (stats.py:43-111), for N environments stepped in lock-step on one GPU.
 
-The world model is the planner's own (see ``stmpc_sim_*`` in include/stmpc.h), not SUMO: results are comparable with the
-reference's reported numbers (experiment_data/saved_data.csv) as DISTRIBUTIONS only.  Every tick is: planner view ->
+The world restates the SUMO scenario the reference configures (Krauss vehicles of the "simple traffic distribution", the ego under
+speed mode 22; see ``stmpc_sim_*`` in include/stmpc.h) but is not SUMO: results are comparable with the reference's reported numbers
+(experiment_data/saved_data.csv) as DISTRIBUTIONS only.  Every tick is: planner view ->
 controller (``st.do_st_control`` for all environments in one launch, or the combined controller) -> world step; nothing but a
 periodic "all finished?" flag crosses to the host.
 """
+import os
+
 import numpy as np
 
 from . import _capi, synth
@@ -27,15 +30,19 @@ def ego_start_position():
     return x0 + EGO_START_ARC * ux, y0 + EGO_START_ARC * uy
 
 
-def sim_cfg(seed=0, max_episode_length=100.0):
+def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None):
     S = Settings
     ex, ey = ego_start_position()
     g = lambda name, default: getattr(S, name, default)
     return _capi.SimCfg(tick_length=S.TICK_LENGTH, other_car_speed=g("OTHER_CAR_SPEED", 7.0), base_traffic_interval=g("BASE_TRAFFIC_INTERVAL", 1.2),
                         spawn_x=SPAWN_X, despawn_x=DESPAWN_X, ego_start_x=ex, ego_start_y=ey, arrive_x=ARRIVE_X, sensor_radius=g("SENSOR_RADIUS", 125.0),
                         start_speed=g("START_SPEED", 15.0), start_speed_std=g("START_SPEED_VARIANCE", 5.0), min_start_speed=g("MIN_START_SPEED", 5.0),
-                        max_start_speed=g("MAX_START_SPEED", 25.0), vary_traffic_start_times=int(bool(g("VARY_TRAFFIC_START_TIMES", True))),
-                        randomize_start_speed=int(bool(g("RANDOMIZE_START_SPEED", True))), max_ticks=int(max_episode_length / S.TICK_LENGTH), seed=int(seed))
+                        max_start_speed=g("MAX_START_SPEED", 25.0),
+                        # SUMO vType "normal" of the simple traffic distribution (merge_impossible.rou.xml:3) + SUMO defaults (emergencyDecel, width)
+                        veh_accel=4.5, veh_decel=6.0, veh_min_gap=1.0, veh_tau=0.5, veh_emergency_decel=9.0, veh_length=g("CAR_LENGTH", 5.0), veh_width=1.8, speed_dev=0.0,
+                        vary_traffic_start_times=int(bool(g("VARY_TRAFFIC_START_TIMES", True))),
+                        randomize_start_speed=int(bool(g("RANDOMIZE_START_SPEED", True))), max_ticks=int(max_episode_length / S.TICK_LENGTH),
+                        yield_overlap=int(os.environ.get("STMPC_SIM_YIELD_OVERLAP", "0")) if yield_overlap is None else int(yield_overlap), seed=int(seed))
 
 
 def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0, check_every=16):

@@ -1,0 +1,15 @@
+"""Where do the batched episodes crash?  Final ego states of crashed environments (analysis tool)."""
+import sys; sys.path.insert(0, '.')
+import numpy as np
+import rl_mpc_lanemerging_amd as pkg
+from rl_mpc_lanemerging_amd import episodes, _capi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+for interval in (2.4, 1.8, 1.2):
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT); pkg.apply_overrides(dict(BASE_TRAFFIC_INTERVAL=interval, OTHER_CAR_SPEED=7.0))
+    ctx = _capi.default_context()
+    st = episodes.run_episodes(n, seed=3, controller="st", ctx=ctx)
+    status, ticks, acc, ego4 = ctx.sim_read(n)
+    cr = np.nonzero(status == 2)[0]
+    print("interval", interval, "crashed", cr.size, "of", n, {k: round(float(np.nanmean(v)), 3) for k, v in st.items() if k != "ticks"})
+    for i in cr[:20]:
+        print("   env %4d tick %3d  x %.2f y %.2f v %.2f a %.2f  mean_speed %.2f closest %.2f" % (i, ticks[i], ego4[i, 0], ego4[i, 1], ego4[i, 2], ego4[i, 3], st["mean_speed"][i], st["closest_distance"][i]))
