@@ -34,10 +34,12 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default 4096 for every --gpus N)")
-    ap.add_argument("--workload", choices=["h40a21", "default", "control", "combined"], default="h40a21",
+    ap.add_argument("--workload", choices=["h40a21", "default", "control", "combined", "episodes"], default="h40a21",
                     help="h40a21: BASELINE workload; default: the reference's own lattice; control: st.do_st_control on the "
                          "reference's lattice (lattice search + QP re-sampling + commanded speed); combined: one tick of the "
-                         "RL+MPC combined controller (configs/combined_medium_1.json) with a stand-in policy network")
+                         "RL+MPC combined controller (configs/combined_medium_1.json) with a stand-in policy network; episodes: batched merge "
+                         "environments with configs/train_moderate_1.json's traffic under that controller (BASELINE configs[4] as a labelled "
+                         "throughput demo: the reference has no counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined", type=int, default=2, help="also report the throughput with this many batches in flight (one context, stream and "
                     "output buffers each; 0/1 = skip); the headline value is always one batch at a time")
@@ -146,6 +148,9 @@ def run(args):
     if args.workload == "combined":
         from rl_mpc_lanemerging_amd import combined_bench
         out = combined_bench.run(args, rank, world, dev, dist)
+    elif args.workload == "episodes":
+        from rl_mpc_lanemerging_amd import episodes_bench
+        out = episodes_bench.run(args, rank, world, dev, dist)
     else:
         out = run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, sharding, synth)
 

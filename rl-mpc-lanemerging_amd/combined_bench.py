@@ -39,6 +39,23 @@ def state_vector(torch, S, ego4, k, ox, ov, oa):
     return torch.cat(out + [ego], dim=1)
 
 
+def make_stand_in_policy(torch, S, dev, seed=1234):
+    """STAND-IN for the reference's DDPG actor (ddpg.py:29-34,83-87): 21 -> 400 -> 300 -> 1, ReLU, tanh x MAXIMUM_POSITIVE_JERK, seeded random
+    weights; returns the ``policy(step, ego4, k, ox, ov, oa) -> jerk[N]`` callback ``combined.decide_batch_device`` takes."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    actor = torch.nn.Sequential(torch.nn.Linear(21, 400), torch.nn.ReLU(), torch.nn.Linear(400, 300), torch.nn.ReLU(), torch.nn.Linear(300, 1))
+    with torch.no_grad():
+        for prm in actor.parameters():
+            prm.copy_(torch.empty_like(prm).uniform_(-0.3, 0.3, generator=g))
+    actor = actor.to(dev).double()
+    jmax = float(S.MAXIMUM_POSITIVE_JERK)
+
+    def policy(step, cur_ego4, k_, cur_ox, cur_ov, cur_oa):
+        with torch.no_grad():
+            return jmax * torch.tanh(actor(state_vector(torch, S, cur_ego4, k_, cur_ox, cur_ov, cur_oa)).squeeze(1))
+    return policy
+
+
 def run(args, rank, world, dev, dist):
     import torch
     import rl_mpc_lanemerging_amd as pkg
@@ -54,17 +71,7 @@ def run(args, rank, world, dev, dist):
     ctx = _capi.Context(dev.index or 0)
     d_ego, d_k = torch.as_tensor(ego, device=dev), torch.as_tensor(kc, device=dev)
     d_ox, d_ov = torch.as_tensor(ox, device=dev), torch.as_tensor(ov, device=dev)
-    g = torch.Generator(device="cpu").manual_seed(1234)
-    actor = torch.nn.Sequential(torch.nn.Linear(21, 400), torch.nn.ReLU(), torch.nn.Linear(400, 300), torch.nn.ReLU(), torch.nn.Linear(300, 1))
-    with torch.no_grad():
-        for prm in actor.parameters():
-            prm.copy_(torch.empty_like(prm).uniform_(-0.3, 0.3, generator=g))
-    actor = actor.to(dev).double()
-    jmax = float(S.MAXIMUM_POSITIVE_JERK)
-
-    def policy(step, cur_ego4, k_, cur_ox, cur_ov, cur_oa):
-        with torch.no_grad():
-            return jmax * torch.tanh(actor(state_vector(torch, S, cur_ego4, k_, cur_ox, cur_ov, cur_oa)).squeeze(1))
+    policy = make_stand_in_policy(torch, S, dev)
 
     def tick():
         return combined.decide_batch_device(ctx, params, cfg, d_ego, d_k, d_ox, d_ov, policy, None, torch.cuda.current_stream().cuda_stream)

@@ -45,73 +45,93 @@ def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None):
                         yield_overlap=int(os.environ.get("STMPC_SIM_YIELD_OVERLAP", "0")) if yield_overlap is None else int(yield_overlap), seed=int(seed))
 
 
-def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0, check_every=16):
-    """Run ``n`` merge episodes to the end; returns the per-episode columns of the reference's stats report
-    (``crashed``, ``merged``, ``mean_speed``, ``max_speed``, ``mean_abs_jerk``, ``closest_distance``, ``mean_closest_distance``,
-    ``time_taken``, ``time_to_merge`` (NaN unless merged)) plus ``ticks`` and ``percent_st`` (combined controller only).
+class EpisodeRunner:
+    """N merge episodes stepped in lock-step on the device, one ``tick()`` at a time (``run_episodes`` drives it to the end;
+    ``bench.py --workload episodes`` times its ticks)."""
 
-    controller: "st" = ``st.do_st_control`` every tick (TASK "ST"); "combined" = ``do_combined_control`` with ``policy``
-    (see ``combined.decide_batch_device``)."""
-    import torch
-    from . import combined
-    ctx = ctx or _capi.default_context()
-    params = _capi.Params.from_settings(Settings)
-    cfg = sim_cfg(seed, max_episode_length)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    H = _capi.num_t(params)
-    d_ego5 = torch.zeros((n, 5), dtype=torch.float64, device=dev)
-    d_k = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_ox = torch.zeros((n, kmax), dtype=torch.float64, device=dev)
-    d_ov = torch.zeros((n, kmax), dtype=torch.float64, device=dev)
-    d_path = torch.zeros((n, H), dtype=torch.int32, device=dev)
-    d_bt = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_cost = torch.zeros(n, dtype=torch.float64, device=dev)
-    d_speed = torch.zeros(n, dtype=torch.float64, device=dev)
-    d_fine = torch.zeros((n, _capi.QP_NMAX), dtype=torch.float64, device=dev)
-    d_fine_len = torch.zeros(n, dtype=torch.int32, device=dev)
-    ccfg = _capi.CombinedCfg.from_settings(Settings) if controller == "combined" else None
-    takeovers = torch.zeros(n, dtype=torch.float64, device=dev)
-    controlled = torch.zeros(n, dtype=torch.float64, device=dev)
-    last_rl = torch.ones(n, dtype=torch.int32, device=dev)
-    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
-    ctx.sim_init(cfg, n)
-    for tick in range(cfg.max_ticks + 1):
-        ctx.sim_view(cfg, n, kmax, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr())
-        if controller == "st":
-            ctx.st_control_batch_device(params, Settings.TICK_LENGTH, n, kmax, d_ego5.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
-                                        d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_speed.data_ptr(), d_fine.data_ptr(), d_fine_len.data_ptr(), 0)
-            cmd = d_speed
+    def __init__(self, n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0):
+        import torch
+        self.torch = torch
+        self.n, self.kmax, self.controller, self.policy = int(n), int(kmax), controller, policy
+        self.ctx = ctx or _capi.default_context()
+        self.params = _capi.Params.from_settings(Settings)
+        self.cfg = sim_cfg(seed, max_episode_length)
+        self.tick_length = Settings.TICK_LENGTH
+        dev = torch.device("cuda", torch.cuda.current_device())
+        H = _capi.num_t(self.params)
+        z = lambda *shape, dtype=torch.float64: torch.zeros(shape, dtype=dtype, device=dev)
+        self.d_ego5, self.d_k, self.d_ox, self.d_ov = z(n, 5), z(n, dtype=torch.int32), z(n, kmax), z(n, kmax)
+        self.d_path, self.d_bt, self.d_cost, self.d_speed = z(n, H, dtype=torch.int32), z(n, dtype=torch.int32), z(n), z(n)
+        self.d_fine, self.d_fine_len = z(n, _capi.QP_NMAX), z(n, dtype=torch.int32)
+        self.ccfg = _capi.CombinedCfg.from_settings(Settings) if controller == "combined" else None
+        self.takeovers, self.controlled = z(n), z(n)
+        self.last_rl = torch.ones(n, dtype=torch.int32, device=dev)
+        self.d_status = z(n, dtype=torch.int32)
+        self.ticks_done = 0
+        self.ctx.sim_init(self.cfg, n)
+
+    def tick(self):
+        """Planner view -> controller -> world step for every environment (finished environments idle)."""
+        from . import combined
+        torch, ctx, n, kmax = self.torch, self.ctx, self.n, self.kmax
+        ctx.sim_view(self.cfg, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr())
+        if self.controller == "st":
+            ctx.st_control_batch_device(self.params, self.tick_length, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr(),
+                                        self.d_path.data_ptr(), self.d_bt.data_ptr(), self.d_cost.data_ptr(), self.d_speed.data_ptr(), self.d_fine.data_ptr(),
+                                        self.d_fine_len.data_ptr(), 0)
+            cmd = self.d_speed
         else:
-            d = combined.decide_batch_device(ctx, params, ccfg, d_ego5, d_k, d_ox, d_ov, policy, last_rl)
+            d = combined.decide_batch_device(ctx, self.params, self.ccfg, self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.policy, self.last_rl)
             cmd = d["speed"]
             # per-episode takeover share (the reference's stats count the ticks of the episode itself): finished environments keep
             # returning their final state from sim_view, their repeated decisions must not be counted
-            ctx.sim_status_device(n, d_status.data_ptr())
-            running = (d_status == 0).to(torch.float64)
-            takeovers += d["takeover"].to(torch.float64) * running
-            controlled += running
-            last_rl = (d["takeover"] == 0).to(torch.int32)
-        ctx.sim_step(params, cfg, n, cmd.data_ptr())
-        if tick % check_every == check_every - 1:
-            status, _, _, _ = ctx.sim_read(n)
-            ctx.check_error()          # (an asynchronous solver / QP error of the ticks since the last check)
-            if (status != 0).all():
-                break
-    status, ticks, acc, _ = ctx.sim_read(n)
-    ctx.check_error()
-    samples = np.maximum(acc[:, 4], 1.0)
-    # mean |jerk| as the reference reports it: its jerk history holds a 0 for the first tick (control.py:284-287) and the mean is taken
-    # over all ticks (stats.py:60) -- n samples, not n - 1 jerk terms
-    out = {"crashed": (status == 2).astype(np.float64), "merged": (status == 1).astype(np.float64), "timed_out": (status == 3).astype(np.float64),
-           "mean_speed": acc[:, 0] / samples, "max_speed": acc[:, 1], "mean_abs_jerk": acc[:, 2] / samples,
-           "closest_distance": np.where(acc[:, 7] > 0, acc[:, 5], np.nan), "mean_closest_distance": np.where(acc[:, 7] > 0, acc[:, 6] / np.maximum(acc[:, 7], 1.0), np.nan),
-           "time_taken": ticks * Settings.TICK_LENGTH, "ticks": ticks}
-    out["time_to_merge"] = np.where(status == 1, out["time_taken"], np.nan)
-    if controller == "combined":
-        out["percent_st"] = (takeovers / torch.clamp(controlled, min=1.0)).cpu().numpy()
-    return out
+            ctx.sim_status_device(n, self.d_status.data_ptr())
+            running = (self.d_status == 0).to(torch.float64)
+            self.takeovers += d["takeover"].to(torch.float64) * running
+            self.controlled += running
+            self.last_rl = (d["takeover"] == 0).to(torch.int32)
+        ctx.sim_step(self.params, self.cfg, n, cmd.data_ptr())
+        self.ticks_done += 1
+
+    def status(self):
+        """Host copy of the status words (synchronises) after raising any latched device-side error."""
+        status, _, _, _ = self.ctx.sim_read(self.n)
+        self.ctx.check_error()          # (an asynchronous solver / QP error of the ticks since the last check)
+        return status
+
+    def result(self):
+        status, ticks, acc, ego4 = self.ctx.sim_read(self.n)
+        self.ctx.check_error()
+        samples = np.maximum(acc[:, 4], 1.0)
+        # mean |jerk| as the reference reports it: its jerk history holds a 0 for the first tick (control.py:284-287) and the mean is taken
+        # over all ticks (stats.py:60) -- n samples, not n - 1 jerk terms
+        out = {"crashed": (status == 2).astype(np.float64), "merged": (status == 1).astype(np.float64), "timed_out": (status == 3).astype(np.float64),
+               "mean_speed": acc[:, 0] / samples, "max_speed": acc[:, 1], "mean_abs_jerk": acc[:, 2] / samples,
+               "closest_distance": np.where(acc[:, 7] > 0, acc[:, 5], np.nan), "mean_closest_distance": np.where(acc[:, 7] > 0, acc[:, 6] / np.maximum(acc[:, 7], 1.0), np.nan),
+               "time_taken": ticks * self.tick_length, "ticks": ticks, "status": status, "ego4": ego4}
+        out["time_to_merge"] = np.where(status == 1, out["time_taken"], np.nan)
+        if self.controller == "combined":
+            out["percent_st"] = (self.takeovers / self.torch.clamp(self.controlled, min=1.0)).cpu().numpy()
+        return out
+
+
+def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0, check_every=16, max_ticks=None):
+    """Run ``n`` merge episodes to the end (or for ``max_ticks`` ticks); returns the per-episode columns of the reference's stats report
+    (``crashed``, ``merged``, ``mean_speed``, ``max_speed``, ``mean_abs_jerk``, ``closest_distance``, ``mean_closest_distance``,
+    ``time_taken``, ``time_to_merge`` (NaN unless merged)) plus ``ticks``, ``status`` (0 still running), ``ego4`` and ``percent_st``
+    (combined controller only).
+
+    controller: "st" = ``st.do_st_control`` every tick (TASK "ST"); "combined" = ``do_combined_control`` with ``policy``
+    (see ``combined.decide_batch_device``)."""
+    r = EpisodeRunner(n, seed, controller, policy, ctx, kmax, max_episode_length)
+    limit = r.cfg.max_ticks + 1 if max_ticks is None else min(int(max_ticks), r.cfg.max_ticks + 1)
+    for tick in range(limit):
+        r.tick()
+        if tick % check_every == check_every - 1 and (r.status() != 0).all():
+            break
+    return r.result()
 
 
 def summary(stats):
     """Column means as the reference's report rows hold them (stats.py:145-158)."""
-    return {k: float(np.nanmean(v)) for k, v in stats.items() if k != "ticks"}
+    return {k: float(np.nanmean(v)) for k, v in stats.items() if k not in ("ticks", "status", "ego4")}

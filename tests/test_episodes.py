@@ -36,3 +36,29 @@ def test_st_episodes_match_the_reference_statistically(interval, gpu_ctx, restor
         st2 = episodes.run_episodes(256, seed=7, controller="st", ctx=gpu_ctx)
         st3 = episodes.run_episodes(256, seed=7, controller="st", ctx=gpu_ctx)
         assert np.array_equal(st3["ticks"], st2["ticks"]) and np.array_equal(st3["mean_speed"], st2["mean_speed"])
+
+
+@pytest.mark.gpu
+def test_combined_controller_environments_config5_demo(gpu_ctx, restore_settings):
+    """BASELINE configs[4] (configs/train_moderate_1.json) has no counterpart in the reference (its training never calls the solver): what
+    exists is the environment side -- batched merge environments with that config's traffic under the combined RL + MPC controller
+    (stand-in actor).  64 environments for 50 ticks: deterministic, and the status / tick bookkeeping is consistent."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import combined_bench, episodes, episodes_bench
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1)
+    pkg.apply_overrides(episodes_bench.TRAIN_MODERATE_1_ENV)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    runs = []
+    for _ in range(2):
+        policy = combined_bench.make_stand_in_policy(torch, pkg.Settings, dev)
+        runs.append(episodes.run_episodes(64, seed=11, controller="combined", policy=policy, ctx=gpu_ctx, kmax=16, max_ticks=50))
+    a, b = runs
+    for key in ("status", "ticks", "ego4", "mean_speed", "percent_st"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    assert set(np.unique(a["status"])) <= {0, 1, 2, 3}
+    assert (a["ticks"][a["status"] == 0] == 50).all() and (a["ticks"] <= 50).all() and (a["ticks"] >= 1).all()
+    assert ((a["percent_st"] >= 0) & (a["percent_st"] <= 1)).all()
+    assert (a["ego4"][:, 0] > episodes.ego_start_position()[0]).all()              # every ego moved
+    assert np.isnan(a["time_to_merge"][a["status"] != 1]).all()
