@@ -113,6 +113,7 @@ typedef struct stmpc_stats {
     int64_t nodes_bound;     /* lattice nodes expanded by the bounding pre-passes */
     double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
     double  dp_kernel_ms;    /* device time of the LDS lattice-DP kernel launches (all LDS tiers) */
+    int64_t guided;          /* episodes whose bound came from the guided attempt (a tube around the unobstructed optimum) */
 } stmpc_stats;
 
 /* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */

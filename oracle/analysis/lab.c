@@ -62,6 +62,12 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             if (key < kmin) kmin = key;
         }
         { for (int i = 0; i < cnt; i++) { if (ents[i].key <= kmin * 1.003) out->flat3++; if (ents[i].key <= kmin * 1.01) out->flat10++; if (ents[i].key <= kmin * 1.03) out->flat30++; } }
+        if (cfg->hmode == 9 && lab_watch) {
+            /* tube around a guide path (lab_set_watch): only the cells within `twin` cells of the guide's cell of this layer; the band applies on top */
+            int m = 0; const int c0 = lab_watch[t];
+            for (int i = 0; i < cnt; i++) { int dd = ents[i].s - c0; if (dd < 0) dd = -dd; if (dd <= cfg->twin && (cfg->band <= 0 || ents[i].key <= kmin + cfg->band)) ents[m++] = ents[i]; }
+            cnt = m;
+        } else
         if (cfg->band > 0 && cfg->hmode == 3) {
             /* mixed band selection as the kernel can do it in one scan: f within its band OR g within its band; each band is
              * steered towards cap/2 nodes per layer */
@@ -157,7 +163,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
                 if (hi > S) hi = S;
                 if (hi <= lo) continue;
                 int nlo2 = lo < tlo ? lo : tlo, nhi2 = hi > thi ? hi : thi;
-                if (cfg->twin > 0 && nhi2 - nlo2 > cfg->twin) { q0 = q + 1; out->tspan_over++; break; }
+                if (cfg->twin > 0 && cfg->hmode != 9 && nhi2 - nlo2 > cfg->twin) { q0 = q + 1; out->tspan_over++; break; }
                 tlo = nlo2; thi = nhi2;
             }
             if (thi - tlo > out->tspan) out->tspan = thi - tlo;

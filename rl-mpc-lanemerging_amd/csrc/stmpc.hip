@@ -175,6 +175,8 @@ struct stmpc_ctx {
     // STMPC_CU_RESERVE=n (multiple of 8, experiment): n compute units are kept out of the first window's launch and host the second
     // window's workgroups from the start of the step (CU-masked streams); 0 = off
     int cu_reserve = 0;
+    int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
+    DevBuf guide_tab, guide_cells; double guide_key[12] = {0}; int guide_imax = 0, guide_D = 0, guide_H = 0; bool guide_ok = false;
     double retry_mult[3] = {1.02, 1.08, 1.3};   // STMPC_RETRY="a,b,c"
     int retire_cus = 0, retire_at = 75;   // STMPC_RETIRE_CUS=k, STMPC_RETIRE_AT=percent of N: k compute units leave the first launch once fewer than that many tasks are left (see SolveArgs::cu_tab)
     DevBuf cu_tab;
@@ -285,6 +287,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     }
     if (!c->aux_stream) c->overlap = 0;          // no side stream: the tiers simply run one after the other
     if (c->sticky.ensure(2 * sizeof(unsigned)) || hipMemset(c->sticky.p, 0, 2 * sizeof(unsigned)) != hipSuccess) { stmpc_destroy(c); return fail(STMPC_ENOMEM, "device allocation failed"); }
+    if (const char *w = getenv("STMPC_TUBE")) { int v = atoi(w); if (v >= 0 && v <= 4096) c->tube_w = v; }
     if (const char *w = getenv("STMPC_RETRY")) { double x[3]; if (sscanf(w, "%lf,%lf,%lf", &x[0], &x[1], &x[2]) == 3 && x[0] > 1.0 && x[1] > 1.0 && x[2] > 1.0) for (int i = 0; i < 3; ++i) c->retry_mult[i] = x[i]; }
     if (const char *w = getenv("STMPC_RETIRE_CUS")) { int v = atoi(w); if (v >= 0 && v < 256) c->retire_cus = v; }
     if (const char *w = getenv("STMPC_RETIRE_AT")) { int v = atoi(w); if (v >= 1 && v <= 200) c->retire_at = v; }
@@ -315,7 +318,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
+    DevBuf *all[] = {&c->guide_tab, &c->guide_cells, &c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
@@ -411,12 +414,68 @@ int make_devp(const stmpc_params *p, DevP *d) {
     return STMPC_OK;
 }
 
+
+// Table of the guided bounding attempt (SolveArgs::guide_tab): the optimal step sequence of the OBSTACLE-FREE problem from every lattice state
+// (i1 = cells covered in the last layer, d = i1 - cells covered in the layer before), by backward dynamic programming over the true state
+// (speed, acceleration) -- not the reference's history-collapsed search, whose answer it only approximates: the table centres a search, it
+// never supplies a cost.  Ranges are st_cy.pyx:65-75 in cell units, shrunk by 1e-6 cell; costs st_cy.pyx:46-50 without the gap term.
+// Returns false (no table: the attempt is skipped) for parameter sets whose state space does not fit a byte per step.
+bool build_guide_table(const DevP &dp, std::vector<unsigned char> &tab, int &imax_out, int &D_out) {
+    const int H = dp.H;
+    const double ds = dp.ds, dt = dp.dt, u = ds / dt;
+    if (H < 3 || !(ds > 0) || !(dt > 0)) return false;
+    const int imax = (int)floor(dp.v_max * dt / ds + 1e-9);
+    const int D = (int)ceil(fmax(fabs(dp.a_min), fabs(dp.a_max)) * dt * dt / ds) + 1;
+    if (imax < 1 || imax > 254 || D > 60) return false;
+    const int nd = 2 * D + 1, nS = (imax + 1) * nd, R = H - 1;
+    std::vector<double> Fp((size_t)nS, 0.0), Fc((size_t)nS);
+    std::vector<unsigned char> pol((size_t)(R + 1) * nS, 255);
+    for (int r = 1; r <= R; ++r) {
+        for (int i1 = 0; i1 <= imax; ++i1) for (int dd = -D; dd <= D; ++dd) {
+            const int st = i1 * nd + dd + D, i2 = i1 - dd;
+            Fc[st] = INFINITY;
+            if (i2 < 0 || i2 > imax) continue;
+            const double v = i1 * u, pv = i2 * u, a = (v - pv) / dt;
+            const double lo_a = fmax(a + dp.j_min * dt, dp.a_min), hi_a = fmin(a + dp.j_max * dt, dp.a_max);
+            const double lo_v = fmax(v + lo_a * dt, 0.0), hi_v = fmin(v + hi_a * dt, dp.v_max);
+            int lo = (int)ceil(lo_v * dt / ds + 1e-6), hi = (int)floor(hi_v * dt / ds - 1e-6);
+            lo = lo < i1 - D ? i1 - D : lo; lo = lo < 0 ? 0 : lo;
+            hi = hi > i1 + D ? i1 + D : hi; hi = hi > imax ? imax : hi;
+            double best = INFINITY; int arg = 255;
+            for (int i0 = lo; i0 <= hi; ++i0) {
+                const double vv = i0 * u - dp.v_des, aa = (i0 - i1) * u / dt, jj = (i0 - 2 * i1 + i2) * u / (dt * dt);
+                const double tot = dp.v_w * vv * vv + dp.a_w * aa * aa + dp.j_w * jj * jj + Fp[(size_t)i0 * nd + (i0 - i1 + D)];
+                if (tot < best) { best = tot; arg = i0; }
+            }
+            Fc[st] = best; pol[(size_t)r * nS + st] = (unsigned char)arg;
+        }
+        Fp.swap(Fc);
+    }
+    tab.assign((size_t)nS * R, 255);
+    for (int i1 = 0; i1 <= imax; ++i1) for (int dd = -D; dd <= D; ++dd) {
+        int c1 = i1, c2 = i1 - dd;
+        if (c2 < 0 || c2 > imax) continue;
+        unsigned char *row = &tab[(size_t)(i1 * nd + dd + D) * R];
+        for (int t = 1; t <= R; ++t) {
+            const int dcur = c1 - c2;
+            if (dcur < -D || dcur > D) break;
+            const int i0 = pol[(size_t)(R - t + 1) * nS + c1 * nd + dcur + D];
+            if (i0 == 255) break;
+            row[t - 1] = (unsigned char)i0;
+            c2 = c1; c1 = i0;
+        }
+    }
+    imax_out = imax; D_out = D;
+    return true;
+}
+
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
                     CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st,
-                    unsigned *sticky = nullptr) {
+                    unsigned *sticky = nullptr, const unsigned char *guide_tab = nullptr, int guide_imax = 0, int guide_D = 0, u16 *guide = nullptr) {
     int blocks = (N + 63) / 64;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky);
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky,
+                       guide_tab, guide_imax, guide_D, guide);
 }
 
 }  // namespace
@@ -557,10 +616,25 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const bool heavy_first = split && c->heavy_first;
     if (heavy_first && (rc = c->prio_key.ensure((size_t)N))) return rc;
     unsigned char *prio_key = heavy_first ? c->prio_key.as<unsigned char>() : nullptr;
+    const unsigned char *g_tab = nullptr; u16 *g_cells = nullptr;
+    if (prune_on && c->tube_w > 0) {
+        // guided bounding attempt: the table depends on the dynamics and the cost weights only; rebuilt when they change (a few ms on the host)
+        const double key[12] = {dp.ds, dp.dt, dp.v_w, dp.a_w, dp.j_w, dp.v_des, dp.v_max, dp.a_min, dp.a_max, dp.j_min, dp.j_max, (double)H};
+        if (memcmp(key, c->guide_key, sizeof key) != 0) {
+            memcpy(c->guide_key, key, sizeof key);
+            std::vector<unsigned char> tab;
+            c->guide_ok = build_guide_table(dp, tab, c->guide_imax, c->guide_D);
+            if (c->guide_ok) {
+                if ((rc = c->guide_tab.ensure(tab.size()))) return rc;
+                HIPCHK(hipMemcpy(c->guide_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+            }
+        }
+        if (c->guide_ok) { if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc; g_tab = c->guide_tab.as<unsigned char>(); g_cells = c->guide_cells.as<u16>(); }
+    }
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>());
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -586,6 +660,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     }
     a.band_cap = c->band_cap;
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
+    a.guide = g_cells; a.tube_w = c->tube_w;
     a.force_general = c->force_general ? 1 : 0;
     a.gsh_max = c->gsh_max;
     a.zl_dt = c->fd2_zl[0]; a.zl_dt2 = c->fd2_zl[1]; a.zl_dt3 = c->fd2_zl[2];
@@ -746,6 +821,7 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         c->stats.hbm_tier = (c->last_has_hbm && c->last_nt >= 2) ? cnt[4 * (c->last_nt - 1)] : 0;
         c->stats.fast_path = c->stats.episodes - cnt[4];
         c->stats.retries = cnt[STMPC_CNT_RETRY];
+        c->stats.guided = cnt[STMPC_CNT_GUIDED];
         c->stats.nodes_exact = cnt[STMPC_CNT_NODES_EXACT];
         c->stats.nodes_bound = cnt[STMPC_CNT_NODES_BOUND];
         c->stats.solve_ms = ms_all;

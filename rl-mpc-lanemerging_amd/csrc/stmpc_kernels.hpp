@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */,
                                                 int *resume_t /* [N] or null: zeroed here */,
                                                 unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */,
-                                                unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */) {
+                                                unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */,
+                                                const unsigned char *__restrict__ guide_tab /* [(imax+1)*(2D+1)][H-1] steps of the unobstructed optimum, or null */,
+                                                int guide_imax, int guide_D, u16 *guide /* [N][H] out */) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     // the previous solve's error flag is latched before the counters are reused (same wavefront: the read precedes lane 63's store)
     if (e == 0 && sticky && counters[63 /* STMPC_CNT_ERR */]) atomicOr(&sticky[0], 1u);
@@ -265,8 +267,34 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
     double s1 = start_s + p.ds;
     double delta = s1 - start_s;
     double s_last = (S - 1 == 1) ? s1 : start_s + (double)(S - 1) * delta;
+    // Guide of the guided bounding attempt (SolveArgs::guide): the unobstructed optimum from the lattice state nearest to the episode's start
+    // (cells covered per layer at the start speed, and one layer earlier), usable if it stays on the lattice and clear of every vehicle and of
+    // its penalty zone.  Approximate on purpose: it only centres a search whose result is checked like any other bound.
+    const unsigned char *grow = nullptr;
+    bool g_ok = false;
+    int g_cell = 0;
+    if (guide_tab) {
+        const double cps = p.dt / delta;
+        int i1 = (int)rint(s.ev * cps), i2 = (int)rint((s.ev - s.ea * p.dt) * cps);
+        i1 = i1 < 0 ? 0 : (i1 > guide_imax ? guide_imax : i1);
+        int d = i1 - i2; d = d < -guide_D ? -guide_D : (d > guide_D ? guide_D : d);
+        if (i1 - d < 0) d = i1;
+        if (i1 - d > guide_imax) d = i1 - guide_imax;
+        grow = guide_tab + ((size_t)i1 * (2 * guide_D + 1) + (size_t)(d + guide_D)) * (size_t)(p.H - 1);
+        g_ok = true;
+        guide[(size_t)e * p.H] = 0;
+    }
     for (int t = 0; t < p.H; ++t) {
         if (t != 0) dev_predict_without_ego<KMAX>(p, s, p.dt, 5.0);            // st.py:42-43
+        double g_sn = 0.0;
+        if (grow && t != 0) {
+            const int stp = (int)grow[t - 1];
+            g_ok = g_ok && stp != 255;
+            g_cell += stp;
+            g_ok = g_ok && g_cell < S;
+            guide[(size_t)e * p.H + t] = (u16)(g_cell < 65535 ? g_cell : 65535);
+            g_sn = start_s + (double)g_cell * delta;
+        }
         double unc = p.unc[t];
         int dunc = p.dunc[t];
         size_t rowbase = ((size_t)e * p.H + t) * Kmax;
@@ -290,11 +318,16 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                     tab.win[(rowbase + na) * 2 + 0] = imin;
                     tab.win[(rowbase + na) * 2 + 1] = imax;
                     ++na;
+                    if (grow && t != 0) {                                          // the guide's cell of this layer against this vehicle
+                        const double gd = __builtin_fmin(fabs(g_sn - front), fabs(g_sn - back));
+                        if ((g_cell >= imin && g_cell < imax) || gd < p.min_allowed) g_ok = false;
+                    }
                 }
             }
         }
         tab.nact[(size_t)e * p.H + t] = na;
     }
+    if (grow && !g_ok) guide[(size_t)e * p.H] = 0xffff;
 }
 
 // One-step prediction exposed through the C-ABI (stmpc_predict_batch).
@@ -380,6 +413,7 @@ __device__ __forceinline__ double divk(double x, double d, double zh, double zl)
 #define STMPC_CNT_RETRY 62
 #define STMPC_CNT_NODES_EXACT 61
 #define STMPC_CNT_NODES_BOUND 60
+#define STMPC_CNT_GUIDED 58      // bounds that came from the guided attempt
 
 struct SolveArgs {
     DevP p;
@@ -433,6 +467,11 @@ struct SolveArgs {
     // left, the workgroups of the units ranked retire_from and above take no more tasks and exit, so that those units become free
     // WHOLE (a second-window workgroup needs a unit's whole LDS) while the queue of overflowing episodes is still filling, instead
     // of quarter by quarter in the launch's tail.  cu_tab: [512] unit keys, [512] rank + 1, [1] units seen.
+    // Guided bounding pass (round 3): for episodes whose unobstructed optimum -- looked up in a table the host builds per parameter set: the
+    // optimal step sequence of the obstacle-free problem from every lattice state (speed, speed one step earlier) -- meets no vehicle, the first
+    // bounding attempt only expands cells within tube_w of that path.  The guide only centres the search: a poor one costs a short wasted pass.
+    const u16 *guide;      // [N][H] guide cells per layer written by k_predict ([0] = 0xffff: no usable guide), or null = off
+    int tube_w;
     double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
     unsigned *cu_tab;      // null = off
     int retire_from;
@@ -504,7 +543,7 @@ struct WgShared {
     int nlist;
     int work;                             // episode id broadcast / -1 = queue drained
     int rc;
-    int path[STMPC_MAXH];
+    int path[STMPC_MAXH];                 // back-track of the exact pass; guide of a guided bounding pass
 };
 
 enum { PASS_EXACT = 0, PASS_BOUND = 1 };
@@ -583,7 +622,7 @@ template <int NWX> struct WgShape {
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int MODE, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost, unsigned *hist, double *pen,
                        u16 *list, int *chunk_cnt, const double *ltab_e, const int *ltab_w, const int *ltab_n,
-                       u64 ubits, double band, bool hardsoft, PassOut &out, const int t_start = 0) {
+                       u64 ubits, double band, bool hardsoft, PassOut &out, const int t_start = 0, const int tube_w = 0) {
     typedef Mem<USE_LDS> M;
     const DevP &p = a.p;
     const int tid = threadIdx.x;
@@ -641,6 +680,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         int my_best_n = 0x7fffffff;
         u64 my_min_tot = ~0ull;
         u64 thr = ubits;
+        int tube_c = 0, tube_lo = 0, tube_hi = 0x7fffffff;       // guided bounding pass: centre of this layer's tube, cell range of the next layer's
+        if constexpr (MODE == PASS_BOUND) {
+            if (tube_w > 0) {
+                tube_c = sh.path[t];
+                const int c1 = sh.path[t + 1 < H ? t + 1 : t];
+                tube_lo = c1 - tube_w; tube_hi = c1 + tube_w + 1;
+            }
+        }
         if constexpr (MODE == PASS_BOUND) {
             // (cells of this pass hold (fp32 cost) << 32 | history, see below: unsigned order = cost order)
             const float lim = __uint_as_float((unsigned)(lmin >> 32)) + (float)bandt;
@@ -763,7 +810,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 const int i = top0 - 64 * (jc + 1) + lane;
                 const u64 cb = ((i >= wlo) & (i < whi)) ? M::ld64(&cost[i & WM]) : INF_BITS;
                 const bool reached = cb < INF_BITS;
-                const bool act = cb <= thr && reached;
+                bool act = cb <= thr && reached;
+                if constexpr (MODE == PASS_BOUND) { if (tube_w > 0) { const int dg = i - tube_c; act = act && dg <= tube_w && dg >= -tube_w; } }
                 pruned_l |= reached && !act;
                 const u64 amask = __ballot(act);
                 if (act) {
@@ -941,6 +989,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             else if (nlo_ >= hi) { lo = hi - 1; }
                             else { hi = lo + 1; }
                         } else { q_smin = sv; q_base = Cf; }      // (no quadratic part: the edge cost is the gap penalty alone)
+                        if (tube_w > 0) { lo = lo > tube_lo ? lo : tube_lo; hi = hi < tube_hi ? hi : tube_hi; }      // targets outside the next layer's tube would not be selected anyway
                     }
                     if (lo >= hi) { lo = 0; hi = 0; }
                 }
@@ -1227,12 +1276,20 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             // upper bound of the terminal cost from a cheap banded search (two attempts), see dp_pass
             // (one call site in a loop: a second inlined copy of the pass would add a third to the kernel's code size)
             int rc = 0, bn = 0;
-            for (int att = 0; att < 2; ++att) {
+            // attempt -1 (guided): only where the unobstructed optimum is clear of the traffic, inside a tube around it
+            bool guided = false;
+            if (a.guide != nullptr) {                         // (written by k_predict: cells per layer, first entry 0xffff = not usable)
+                __syncthreads();
+                if (tid < H) sh.path[tid] = (int)a.guide[(size_t)e * H + tid];
+                __syncthreads();
+                guided = sh.path[0] != 0xffff;
+            }
+            for (int att = guided ? -1 : 0; att < 2; ++att) {
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN, 0, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
-                                                                                   att == 0 ? a.band : a.band * a.band2_mult, att == 0, out);
+                                                                                   att <= 0 ? a.band : a.band * a.band2_mult, att <= 0, out, 0, att < 0 ? a.tube_w : 0);
                 bn += out.nodes;
-                if (rc != 0) break;
-                if (out.best_t == H - 1) { ubits = out.best_bits; break; }
+                if (rc != 0) { if (att < 0) { rc = 0; continue; } break; }      // (a tube that does not fit the window: go on with the ordinary attempts)
+                if (out.best_t == H - 1) { ubits = out.best_bits; if (att < 0 && tid == 0) atomicAdd(&a.counters[STMPC_CNT_GUIDED], 1u); break; }
             }
             if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);
             if (rc != 0 && !a.last_tier) {
