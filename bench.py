@@ -25,7 +25,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak
-MEASURED = os.path.join(REPO, "profiles", "r2", "measured.json")   # counters bench.py cannot regenerate itself (rocprofv3 passes)
+MEASURED = os.path.join(REPO, "profiles", "r3", "measured.json")   # counters bench.py cannot regenerate itself (rocprofv3 passes)
 
 
 def parse_args():
@@ -345,7 +345,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
            "rccl_ranks": (dist.get_world_size() if use_dist else 0),
            "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
            "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
-                     "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]),
+                     "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]), "guided_bounds": int(tier_stats.get("guided", 0)),
                      "nodes_expanded_per_solve": (tier_stats["nodes_exact"] + tier_stats["nodes_bound"]) / n}}
 
     if pipelined:
@@ -406,7 +406,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         out["parity_vs_oracle"] = {"episodes": mp, **parity}
         # fp64 work: (1) what the reference's algorithm does (heap Dijkstra: settled nodes, relaxed edges, counted by the oracle on
         # the same states), (2) what the full layered DP would do, (3) what the kernel executed (node counters of this run; candidate
-        # evaluations per node from the analysis build's counters in profiles/r2/measured.json)
+        # evaluations per node from the analysis build's counters in profiles/r3/measured.json)
         hp, ly = counts["heap"], counts["layered"]
         mh = hp["path_idx"].shape[0]
         ref_flops = (27 * hp["edges"] + 26 * hp["nodes"]) / mh + 40 * K * H
@@ -433,7 +433,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
             out["issue"] = {"valu_wave_instructions_per_step": vi, "salu_wave_instructions_per_step": si,
                             "valu_issue_slots_per_step": 1024 * dp_ms * 1e-3 * 2.4e9 / 4.0,
                             "valu_busy_frac": vi * 4.0 / (1024 * dp_ms * 1e-3 * 2.4e9),
-                            "source": "profiles/r2/measured.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., scripts/profile_gpu.sh), kernel time of this run"}
+                            "source": "profiles/r3/measured.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., scripts/profile_gpu.sh), kernel time of this run"}
     return out
 
 

@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
         tab.nact[(size_t)e * p.H + t] = na;
     }
     if (grow && !g_ok) guide[(size_t)e * p.H] = 0xffff;
+    // Episodes whose unobstructed optimum is clear of the traffic behave: their bounds are tight, their exact passes do not overflow the window (offline:
+    // none of 245).  The others hold every long chain of a step (poor bound -> wide search -> window overflow -> second window), so they go first.
+    if (prio_key && grow) prio_key[e] = (unsigned char)((g_ok ? 128 : 0) + (prio_key[e] >> 1));
 }
 
 // One-step prediction exposed through the C-ABI (stmpc_predict_batch).

@@ -76,6 +76,25 @@ def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("tube", ["0", "8", "96", "4000"])
+def test_guided_bounding_attempt_is_exact(tube, restore_settings, monkeypatch):
+    """The guided bounding attempt (a tube around the unobstructed optimum, guide cells from the predictor kernel) only supplies a bound: whatever
+    the tube's width -- off, too narrow to hold a path, the default, wider than the lattice -- every output bit is the reference's; and on the wide
+    lattice it does supply the bound for a good part of the states."""
+    from rl_mpc_lanemerging_amd import _capi, st
+    monkeypatch.setenv("STMPC_TUBE", tube)
+    ctx = _capi.Context(0)
+    for fname in STATE_FILES:
+        g = load_golden(fname)
+        p, op = settings_from_golden(g)
+        res = st.solve_arrays(g["ego"], g["k_count"], g["other_x"], g["other_v"], p, ctx)
+        _check(res, g, g["t_values"].size)
+        if fname == "golden_h40a21.npz":
+            guided = ctx.stats()["guided"]
+            assert guided == 0 if tube == "0" else guided > g["ego"].shape[0] // 8
+    ctx.close()
+
+
 def test_general_lattice_form_routing(restore_settings, monkeypatch):
     """Episodes whose lattice is not start + n*delta (not reachable through np.arange, but guarded) are sent to the
     last tier, which evaluates the general form: force that route for every episode and compare."""
