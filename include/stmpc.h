@@ -28,11 +28,12 @@
  * Concurrency: a context owns one set of scratch buffers, work counters and overflow queues; AT MOST ONE batched call may be
  * in flight per context (calls on one stream are naturally ordered; calls on different streams, or from different host
  * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only.
- * Scratch: the wide-lattice solver keeps 2 bytes per lattice cell of the first window and time layer per episode for its
- * back-pointers when it may continue an overflowing search in the next window (N * H * 2048 * 2 B: 0.66 GB for 4096 episodes at
- * H = 40, 1.3 GB for 8192, released by stmpc_destroy) plus a 24 KB checkpoint slot per episode.  The solver takes that only while it
- * is at most a quarter of the device memory that is free at the time (hipMemGetInfo) and at most 8 GB; otherwise, or if the allocation
- * fails, it falls back to per-workgroup storage (restarting instead of continuing overflowing episodes) -- results are the same bits.
+ * Scratch: the wide-lattice solver keeps one back-pointer per lattice cell of the first window and time layer per episode when it may continue
+ * an overflowing search in the next window -- one byte (the distance to the predecessor) when no step of the dynamics exceeds 255 cells, else
+ * two: N * H * 2048 B = 0.33 GB for 4096 episodes at H = 40, 0.66 GB for 8192, released by stmpc_destroy -- plus a 24 KB checkpoint slot per
+ * episode.  The solver takes that only while it is at most a quarter of the device memory that is free at the time (hipMemGetInfo) and at most
+ * 8 GB; otherwise, or if the allocation fails, it falls back to per-workgroup storage (restarting instead of continuing overflowing episodes) --
+ * results are the same bits.
  *
  * Arithmetic contract.  Every operation of the reference's search (st_cy.pyx:34-93) is evaluated as one IEEE-754 fp64 operation in the
  * reference's order; the library is built with FP contraction off.  Two kinds of division are formed without the hardware's division

@@ -564,7 +564,10 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
     // episode (N x H x W0 x 2 B) instead of per resident workgroup
-    const size_t bp0_per_episode = (size_t)N * H * tierW[0] * sizeof(u16);
+    // back-pointers: one byte (distance to the predecessor) when no step of the dynamics exceeds 255 cells, else two (its cell)
+    const bool bp_rel8 = ceil(dp.v_max * dp.dt / dp.ds) + 4.0 <= 255.0 && getenv("STMPC_BP16") == nullptr;
+    const size_t bp_elem = bp_rel8 ? 1 : sizeof(u16);
+    const size_t bp0_per_episode = (size_t)N * H * tierW[0] * bp_elem;
     bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
                   bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
     if (resume && c->bp_tier[0].cap < bp0_per_episode) {
@@ -588,7 +591,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         }
     }
     for (int k = 0; k < nt; ++k) {
-        const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * sizeof(u16);
+        const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * bp_elem;
         if ((rc = c->bp_tier[k].ensure(need))) return rc;
     }
     int *resume_t = resume ? c->resume_t.as<int>() : nullptr;
@@ -661,6 +664,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.band_cap = c->band_cap;
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
     a.guide = g_cells; a.tube_w = c->tube_w;
+    a.bp_rel8 = bp_rel8 ? 1 : 0;
     a.force_general = c->force_general ? 1 : 0;
     a.gsh_max = c->gsh_max;
     a.zl_dt = c->fd2_zl[0]; a.zl_dt2 = c->fd2_zl[1]; a.zl_dt3 = c->fd2_zl[2];

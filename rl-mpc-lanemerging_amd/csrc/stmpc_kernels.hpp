@@ -284,11 +284,22 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
         g_ok = true;
         guide[(size_t)e * p.H] = 0;
     }
+    // the row's steps, fetched up front (independent loads: one memory latency instead of one per layer), four to a register
+    unsigned gsteps[(STMPC_MAXH + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (STMPC_MAXH + 3) / 4; ++q) {
+        unsigned w_ = 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const int t_ = q * 4 + b; if (grow && t_ < p.H - 1) w_ |= (unsigned)grow[t_] << (8 * b); }
+        gsteps[q] = w_;
+    }
     for (int t = 0; t < p.H; ++t) {
         if (t != 0) dev_predict_without_ego<KMAX>(p, s, p.dt, 5.0);            // st.py:42-43
         double g_sn = 0.0;
         if (grow && t != 0) {
-            const int stp = (int)grow[t - 1];
+            int stp = 0;
+#pragma unroll
+            for (int q = 0; q < (STMPC_MAXH + 3) / 4; ++q) if (q == ((t - 1) >> 2)) stp = (int)((gsteps[q] >> (8 * ((t - 1) & 3))) & 0xffu);
             g_ok = g_ok && stp != 255;
             g_cell += stp;
             g_ok = g_ok && g_cell < S;
@@ -440,7 +451,8 @@ struct SolveArgs {
     int S_grid;
     double v0_grid, a0_grid;
     // scratch
-    u16 *bp;               // [blocks][H][W] back-pointers of this tier
+    u16 *bp;               // [blocks][H][W] back-pointers of this tier: the predecessor's cell (2 bytes), or, with bp_rel8, the distance to it in cells (1 byte)
+    int bp_rel8;           // every step of the dynamics is at most 255 cells: back-pointers are stored as one-byte distances (half the scratch and the traffic)
     unsigned char *gscratch;   // HBM-storage variant: [blocks][20*W] bytes
     unsigned *counters;    // [0] tier-0 work counter; [4k] list-k length, [4k+1] list-k work counter; [63] error flag
     int *lists;            // [STMPC_MAX_TIERS][N] episode ids queued for tier k
@@ -1028,7 +1040,12 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 rstep = (64 * kw) >> gsh;
             }
             const bool act = inlist && wave < kw;
-            if constexpr (MODE == PASS_EXACT) { if (act && t > 0 && sub == 0) bp[(size_t)t * W + (i & WM)] = (u16)pr; }
+            if constexpr (MODE == PASS_EXACT) {
+                if (act && t > 0 && sub == 0) {
+                    if (a.bp_rel8) ((unsigned char *)bp)[(size_t)t * W + (i & WM)] = (unsigned char)(i - pr);
+                    else bp[(size_t)t * W + (i & WM)] = (u16)pr;
+                }
+            }
             if (!act) { lo = 0; hi = 0; }
             if (!relax) continue;
             const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
@@ -1241,7 +1258,8 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         // lattice point start+step differs from that goes to the last tier, which is compiled with the general form
         if ((!ep.s1_plain || a.force_general) && phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
     }
-    ep.bp = a.bp + (size_t)(RES == 1 ? e : slot) * H * W;      // RES 1: per episode, the next tier reads them
+    // (RES 1: per episode, the next tier reads them; element size 1 or 2 bytes, see SolveArgs::bp_rel8)
+    ep.bp = (u16 *)((unsigned char *)a.bp + (size_t)(RES == 1 ? e : slot) * H * W * (a.bp_rel8 ? 1 : 2));
     const double start_s = ep.start_s, delta = ep.delta;
     const int S = ep.S;
     auto sval = [&](int n) -> double {
@@ -1342,7 +1360,11 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         int n = best_n;
         for (int t = best_t; t > 0; --t) {
             sh.path[t] = n;
-            if (RES != 2 || t >= t_res) n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.bp_rel8) {
+                const unsigned char *b8 = (RES != 2 || t >= t_res) ? (const unsigned char *)bp + (size_t)t * W + (n & WM)
+                                                                   : (const unsigned char *)a.bp0 + ((size_t)e * H + t) * a.W0 + (n & (a.W0 - 1));
+                n -= (int)__hip_atomic_load(b8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (RES != 2 || t >= t_res) n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else n = __hip_atomic_load(&a.bp0[((size_t)e * H + t) * a.W0 + (n & (a.W0 - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         sh.path[0] = n;
