@@ -176,6 +176,7 @@ struct stmpc_ctx {
     // window's workgroups from the start of the step (CU-masked streams); 0 = off
     int cu_reserve = 0;
     int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
+    std::vector<unsigned char> guide_host;
     DevBuf guide_tab, guide_cells; double guide_key[12] = {0}; int guide_imax = 0, guide_D = 0, guide_H = 0; bool guide_ok = false;
     double retry_mult[3] = {1.02, 1.08, 1.3};   // STMPC_RETRY="a,b,c"
     int retire_cus = 0, retire_at = 75;   // STMPC_RETIRE_CUS=k, STMPC_RETIRE_AT=percent of N: k compute units leave the first launch once fewer than that many tasks are left (see SolveArgs::cu_tab)
@@ -625,11 +626,12 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         const double key[12] = {dp.ds, dp.dt, dp.v_w, dp.a_w, dp.j_w, dp.v_des, dp.v_max, dp.a_min, dp.a_max, dp.j_min, dp.j_max, (double)H};
         if (memcmp(key, c->guide_key, sizeof key) != 0) {
             memcpy(c->guide_key, key, sizeof key);
-            std::vector<unsigned char> tab;
-            c->guide_ok = build_guide_table(dp, tab, c->guide_imax, c->guide_D);
+            // (stream-ordered upload from a buffer the context keeps: an earlier call on this stream may still be reading the previous table)
+            HIPCHK(hipStreamSynchronize(st));
+            c->guide_ok = build_guide_table(dp, c->guide_host, c->guide_imax, c->guide_D);
             if (c->guide_ok) {
-                if ((rc = c->guide_tab.ensure(tab.size()))) return rc;
-                HIPCHK(hipMemcpy(c->guide_tab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+                if ((rc = c->guide_tab.ensure(c->guide_host.size()))) return rc;
+                HIPCHK(hipMemcpyAsync(c->guide_tab.p, c->guide_host.data(), c->guide_host.size(), hipMemcpyHostToDevice, st));
             }
         }
         if (c->guide_ok) { if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc; g_tab = c->guide_tab.as<unsigned char>(); g_cells = c->guide_cells.as<u16>(); }

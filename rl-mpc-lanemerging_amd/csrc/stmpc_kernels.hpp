@@ -284,22 +284,13 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
         g_ok = true;
         guide[(size_t)e * p.H] = 0;
     }
-    // the row's steps, fetched up front (independent loads: one memory latency instead of one per layer), four to a register
-    unsigned gsteps[(STMPC_MAXH + 3) / 4];
-#pragma unroll
-    for (int q = 0; q < (STMPC_MAXH + 3) / 4; ++q) {
-        unsigned w_ = 0u;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { const int t_ = q * 4 + b; if (grow && t_ < p.H - 1) w_ |= (unsigned)grow[t_] << (8 * b); }
-        gsteps[q] = w_;
-    }
+    int g_next = grow ? (int)grow[0] : 0;          // the row's steps are fetched one layer ahead: the load's latency hides behind the layer's work
     for (int t = 0; t < p.H; ++t) {
         if (t != 0) dev_predict_without_ego<KMAX>(p, s, p.dt, 5.0);            // st.py:42-43
         double g_sn = 0.0;
         if (grow && t != 0) {
-            int stp = 0;
-#pragma unroll
-            for (int q = 0; q < (STMPC_MAXH + 3) / 4; ++q) if (q == ((t - 1) >> 2)) stp = (int)((gsteps[q] >> (8 * ((t - 1) & 3))) & 0xffu);
+            const int stp = g_next;
+            if (t < p.H - 1) g_next = (int)grow[t];
             g_ok = g_ok && stp != 255;
             g_cell += stp;
             g_ok = g_ok && g_cell < S;
