@@ -732,6 +732,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 88>), grid, block, lds, lst, a);       \
         } while (0)
+#ifndef STMPC_FAN88
+#define STMPC_FAN88 16      /* candidate slots per barrier pair in the standard second window (it has the registers: 256 VGPRs) */
+#endif
 #define STMPC_LAUNCH_R0(L, FD, KT_, FM, SG)                                                                   \
         do {                                                                                                  \
             if constexpr (L) { if (std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 0); else STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 0); } \
@@ -743,7 +746,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
             if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
                 if (resume && k == 0 && std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
                 else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
-                else if (resume && k == 1 && std_shape2) STMPC_LAUNCH_R88(L, FD, KT_, FM, SG, 2);             \
+                else if (resume && k == 1 && std_shape2) STMPC_LAUNCH_R88(L, FD, KT_, STMPC_FAN88, SG, 2);    \
                 else if (resume && k == 1) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 2);                             \
                 else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                     \
             } else STMPC_LAUNCH_R0(L, FD, KT_, FM, SG);                                                       \

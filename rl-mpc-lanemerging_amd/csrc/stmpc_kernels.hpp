@@ -1119,7 +1119,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
+#ifdef STMPC_UB88
+                constexpr int UB = (NWX == 88) ? STMPC_UB88 : ((FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX));
+#else
                 constexpr int UB = (FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX);   // small batches: slots beyond a wave's widest range are skipped
+#endif
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
                     if (__ballot(cand(cbase + ub) < hi)) {
@@ -1138,7 +1142,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             const double jj = divk<FASTDIV>(sn - three_sv + three_p1 - p2, dt3, r_dt3, zl_dt3);
                             const double dv = v - p.v_des;
                             const double ec = p.v_w * (dv * dv) + p.a_w * (aa * aa) + p.j_w * (jj * jj) + pn[u];
-                            const double tot = C + ec;                       // st_cy.pyx:388
+                            double tot = C + ec;                             // st_cy.pyx:388
+#ifndef STMPC_NO_ILP88
+                            // second window: the workgroup is alone on its unit (two waves per SIMD), so what costs time is the latency of the
+                            // dependent fp64 chain, not issue slots: evaluate every slot of a batch unconditionally (the compiler otherwise sinks
+                            // the evaluation into a per-slot exec-mask region and runs the slots one after the other), four chains in flight
+                            if constexpr (NWX == 88) asm volatile("" : "+v"(tot));
+#endif
                             const bool ok = (n < hi) & (pn[u] >= 0.0);       // st_cy.pyx:379,383
                             tb[ub + u] = ok ? (u64)__double_as_longlong(tot) : ~0ull;
                             STMPC_PH_CAND(ok);
@@ -1450,7 +1460,8 @@ __host__ __device__ inline size_t stmpc_tab_bytes(int H, int KT) { return (size_
 #endif
 // Persistent kernel: workgroups of NW waves pull episodes until the tier's queue is drained.
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
-__global__ void __launch_bounds__(512, (FANMAX <= 12 ? STMPC_MIN_WAVES : 2)) k_solve(SolveArgs a) {
+// (the standard second window -- NWX 88: eight waves, 147 KB of LDS -- is alone on its compute unit, two waves per SIMD: it may use 256 VGPRs)
+__global__ void __launch_bounds__(512, ((FANMAX <= 12 && NWX != 88) ? STMPC_MIN_WAVES : 2)) k_solve(SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ WgShared sh;
     const int tid = threadIdx.x;
