@@ -478,6 +478,7 @@ struct SolveArgs {
     // bounding attempt only expands cells within tube_w of that path.  The guide only centres the search: a poor one costs a short wasted pass.
     const u16 *guide;      // [N][H] guide cells per layer written by k_predict ([0] = 0xffff: no usable guide), or null = off
     int tube_w;
+    int retry_move;        // first window: after this many failed exact passes of an episode the next one runs in the second window (0 = never)
     double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
     unsigned *cu_tab;      // null = off
     int retire_from;
@@ -1345,10 +1346,20 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_EXACT], (unsigned)out.nodes);
         if (out.best_t == H - 1 || !out.pruned) break;
         // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
-        // (its answer is usually within a few per cent of the bound, so grow gently first)
+        // (growth factors: SolveArgs::retry_mult)
         if (attempt >= 3) ubits = INF_BITS;
         else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * (attempt == 0 ? a.retry_mult[0] : (attempt == 1 ? a.retry_mult[1] : a.retry_mult[2])));
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);
+        if constexpr (!GRID && RES == 1) {
+            // A search that has failed retry_move times already is one of the step's longest chains (three passes, each larger than the last):
+            // its next pass goes to the second window, whose workgroup has a compute unit to itself and runs an episode about twice as fast.
+            if (a.retry_move > 0 && attempt + 1 >= a.retry_move && !a.last_tier) {
+                if (tid == 0) { a.ubound[e] = (ubits == 0ull) ? 1ull : ubits; a.resume_t[e] = 0; }
+                __threadfence();
+                __syncthreads();
+                return 1;
+            }
+        }
     }
     const int best_t = out.best_t, best_n = out.best_n;
     const u64 best_bits = out.best_bits;
