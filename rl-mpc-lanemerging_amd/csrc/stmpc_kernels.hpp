@@ -478,6 +478,8 @@ struct SolveArgs {
     // bounding attempt only expands cells within tube_w of that path.  The guide only centres the search: a poor one costs a short wasted pass.
     const u16 *guide;      // [N][H] guide cells per layer written by k_predict ([0] = 0xffff: no usable guide), or null = off
     int tube_w;
+    int prio_mode;         // (experiment: which estimate prio_thr is compared with)
+    int prio_thr;          // first window: an overflowing search with more than this much left (layers x nodes) joins the front class of the next queue; 0 = off
     int retry_move;        // first window: after this many failed exact passes of an episode the next one runs in the second window (0 = never)
     double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
     unsigned *cu_tab;      // null = off
@@ -877,6 +879,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 const int top_src = list_at(0), low_src = smin;
                 if (top_src + a.maxshift - low_src > W) {
                     ckpt_save<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
+                    out.nodes = nlist;          // (nodes of the layer that was saved: what is left to do scales with it, see solve_episode)
                     return 2;
                 }
             }
@@ -1340,6 +1343,16 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 if constexpr (RES == 1) { if (tid == 0) a.resume_t[e] = (rc == 2) ? out.best_t : 0; }   // rc 2: layer out.best_t is saved
                 __threadfence();        // checkpoint, back-pointers, bound: visible before the episode is queued
                 __syncthreads();
+                // Longest first in the next window: what is left of this search is roughly (layers left) x (nodes of the saved layer); above
+                // prio_thr the episode joins the queue's front class (bit 2 of the return code), which the consumers drain first.  The step
+                // ends with the second window's last episode, so the long ones must not start last.
+                if constexpr (RES == 1) {
+                    if (rc == 2 && a.prio_thr > 0) {
+                        const int left = H - 1 - out.best_t;
+                        const int key = a.prio_mode == 1 ? left * 1000 : (a.prio_mode == 2 ? out.nodes * 20 : (a.prio_mode == 3 ? left * left * out.nodes / 16 : left * out.nodes));
+                        if (key > a.prio_thr) return 6;
+                    }
+                }
             }
             return rc;
         }
@@ -1595,7 +1608,7 @@ __global__ void __launch_bounds__(512, ((FANMAX <= 12 && NWX != 88) ? STMPC_MIN_
                 if (!a.last_tier) {
                     atomicAdd(&a.counters[4 * (a.tier + 1)], 1u);
                     const u64 ub = a.ubound ? a.ubound[e] : 0ull;          // written by this thread in solve_episode
-                    const bool heavy = (ub == 0ull || ub == INF_BITS);
+                    const bool heavy = (ub == 0ull || ub == INF_BITS) || (rc & 4) != 0;
                     const unsigned pos = atomicAdd(&a.counters[4 * (a.tier + 1) + (heavy ? 2 : 3)], 1u);
                     int *slot = &a.lists[(size_t)(a.tier + 1) * a.N + (heavy ? pos : (unsigned)a.N - 1u - pos)];
                     __hip_atomic_store(slot, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // after ubound[e]
