@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r3l; mkdir -p $O
-python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
+timeout 300 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 bash scripts/profile_gpu.sh r3 > $O/prof_r3.log 2>&1
 bash scripts/profile_gpu.sh r3_default --workload default > $O/prof_r3_default.log 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench_h40a21.json 2> $O/bench_h40a21.err; tail -c 400 $O/bench_h40a21.json; echo
