@@ -15,4 +15,5 @@ st.solve_arrays(ego, k, ox, ov, p, ctx)
 os.environ["STMPC_DUMP_TIMES"] = out
 r = st.solve_arrays(ego, k, ox, ov, p, ctx)
 s = ctx.stats()
+np.save(out + ".cost.npy", r["cost"])
 print(out, {q: s[q] for q in ("solve_ms", "fallback", "retries", "nodes_exact", "nodes_bound")})
