@@ -22,6 +22,9 @@ typedef struct {
     double divmult;
     int sections;      /* hmode 7: number of position sections with their own band */
     int switch_t;      /* > 0 with band > 0: layers before switch_t expand everything <= U (the exact pass), the band applies from switch_t on */
+    int gpu_round;     /* > 0: expand in the kernel's order (descending rounds of this many sources, candidate slots in lock-step) and count the offers that
+                          could still matter when they are made (flat3: cost <= the cell's value at the start of the round, flat10: at the start of the slot,
+                          flat30: 64-lane groups x slots with at least one such offer; tspan_over: all such groups) */
 } lab_cfg;
 
 typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; double lay_kmin[64], lay_band[64], watch_c[64]; int watch_sel[64]; } lab_out;
@@ -61,7 +64,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             ents[cnt].key = key; ents[cnt].s = s; cnt++;
             if (key < kmin) kmin = key;
         }
-        { for (int i = 0; i < cnt; i++) { if (ents[i].key <= kmin * 1.003) out->flat3++; if (ents[i].key <= kmin * 1.01) out->flat10++; if (ents[i].key <= kmin * 1.03) out->flat30++; } }
+        if (cfg->gpu_round <= 0) { for (int i = 0; i < cnt; i++) { if (ents[i].key <= kmin * 1.003) out->flat3++; if (ents[i].key <= kmin * 1.01) out->flat10++; if (ents[i].key <= kmin * 1.03) out->flat30++; } }
         if (cfg->hmode == 9 && lab_watch) {
             /* tube around a guide path (lab_set_watch): only the cells within `twin` cells of the guide's cell of this layer; the band applies on top */
             int m = 0; const int c0 = lab_watch[t];
@@ -168,6 +171,58 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             }
             if (thi - tlo > out->tspan) out->tspan = thi - tlo;
         }
+        if (cfg->gpu_round > 0) {
+            const int R = cfg->gpu_round;
+            double *snap = (double *)malloc(sizeof(double) * S);
+            for (int r1 = cnt; r1 > q0; r1 -= R) {                 /* sources ents[r0..r1), highest first */
+                const int r0 = r1 - R > q0 ? r1 - R : q0;
+                memcpy(snap, nxt_c, sizeof(double) * S);
+                int maxfan = 0;
+                int *lo_ = (int *)malloc(sizeof(int) * (r1 - r0)), *hi_ = (int *)malloc(sizeof(int) * (r1 - r0));
+                for (int q = r0; q < r1; q++) {
+                    int s = ents[q].s; double mn, mx; int lo, hi;
+                    orc_next_s_range(s_values[s], cur_p1[s], cur_p2[s], delta_t, j_min, j_max, a_min, a_max, v_max, &mn, &mx);
+                    orc_range_indices(start_s, delta_s, mn, mx, &lo, &hi);
+                    if (hi > S) hi = S;
+                    if (cfg->filt && U < 1e300) {      /* the kernel narrows the range to the candidates whose quadratic part stays within U */
+                        double C = cur_c[s], sv = s_values[s];
+                        while (lo < hi) { double sn = s_values[lo]; double v = (sn - sv) / delta_t, a = (sn - 2 * sv + cur_p1[s]) / (delta_t * delta_t), j = (sn - 3 * sv + 3 * cur_p1[s] - cur_p2[s]) / dt3;
+                            if (C + v_w * (v - v_des) * (v - v_des) + a_w * a * a + j_w * j * j > U) lo++; else break; }
+                        while (hi > lo) { double sn = s_values[hi - 1]; double v = (sn - sv) / delta_t, a = (sn - 2 * sv + cur_p1[s]) / (delta_t * delta_t), j = (sn - 3 * sv + 3 * cur_p1[s] - cur_p2[s]) / dt3;
+                            if (C + v_w * (v - v_des) * (v - v_des) + a_w * a * a + j_w * j * j > U) hi--; else break; }
+                    }
+                    lo_[q - r0] = lo; hi_[q - r0] = hi; if (hi - lo > maxfan) maxfan = hi - lo;
+                    nodes++;
+                }
+                for (int k = 0; k < maxfan; k++) {
+                    double *snap2 = (double *)malloc(sizeof(double) * S); memcpy(snap2, nxt_c, sizeof(double) * S);
+                    for (int g1 = r1; g1 > r0; g1 -= 64) {        /* one wave's 64 sources */
+                        int g0 = g1 - 64 > r0 ? g1 - 64 : r0, any = 0, anyoff = 0;
+                        for (int q = g1 - 1; q >= g0; q--) {
+                            int s = ents[q].s, n = lo_[q - r0] + k;
+                            if (n >= hi_[q - r0]) continue;
+                            anyoff = 1;
+                            size_t nat = (size_t)(t + 1) * S + n;
+                            if (obstacles[nat]) continue;
+                            double C = cur_c[s], sv = s_values[s];
+                            double c = C + orc_cost_with_jerk(s_values[n], sv, cur_p1[s], cur_p2[s], delta_t, dt3, distances[nat], min_allowed, v_w, v_des, a_w, j_w, d_w);
+                            edges++;
+                            if (c <= snap[n]) out->flat3++;
+                            if (c <= snap2[n]) { out->flat10++; any = 1; }
+                            if (c < nxt_c[n] || (c == nxt_c[n] && s < prev_n[n])) {
+                                nxt_c[n] = c; prev_n[n] = s; nxt_p1[n] = sv; nxt_p2[n] = cur_p1[s];
+                                if (n < nlo) nlo = n;
+                                if (n + 1 > nhi) nhi = n + 1;
+                            }
+                        }
+                        out->flat30 += any; out->tspan_over += anyoff;
+                    }
+                    free(snap2);
+                }
+                free(lo_); free(hi_);
+            }
+            free(snap);
+        } else
         for (int q = q0; q < cnt; q++) {
             int s = ents[q].s; double C = cur_c[s];
             nodes++; if (cfg->switch_t > 0 && t >= cfg->switch_t) out->tspan_over++;   /* (switch mode: nodes of the completion part) */

@@ -18,7 +18,7 @@ def build():
 
 class Cfg(C.Structure):
     _fields_ = [("U", C.c_double), ("beamK", C.c_int), ("band", C.c_double), ("hmode", C.c_int), ("hscale", C.c_double),
-                ("hardsoft", C.c_int), ("stride", C.c_int), ("cap", C.c_int), ("twin", C.c_int), ("filt", C.c_int), ("divchunk", C.c_int), ("divmult", C.c_double), ("sections", C.c_int), ("switch_t", C.c_int)]
+                ("hardsoft", C.c_int), ("stride", C.c_int), ("cap", C.c_int), ("twin", C.c_int), ("filt", C.c_int), ("divchunk", C.c_int), ("divmult", C.c_double), ("sections", C.c_int), ("switch_t", C.c_int), ("gpu_round", C.c_int)]
 class Out(C.Structure):
     _fields_ = [("nodes", C.c_longlong), ("edges", C.c_longlong), ("maxspan", C.c_longlong), ("maxlayer", C.c_longlong), ("rounds64", C.c_longlong), ("flat3", C.c_longlong), ("flat10", C.c_longlong), ("flat30", C.c_longlong), ("tspan", C.c_longlong), ("tspan_over", C.c_longlong),
                 ("best_t", C.c_int), ("cost", C.c_double), ("complete", C.c_int), ("per_layer", C.c_longlong * 64),
@@ -43,7 +43,7 @@ def _init(wl):
 def run_pass(grid, v0, a0, **kw):
     ob, sv, tv, di = grid
     cfg = Cfg(U=kw.get("U", INF), beamK=kw.get("K", 0), band=kw.get("band", 0.0), hmode=kw.get("hmode", 0), hscale=kw.get("hscale", 1.0),
-              hardsoft=kw.get("hs", 0), stride=kw.get("stride", 1), cap=kw.get("cap", 0), twin=kw.get("twin", 0), filt=kw.get("filt", 0), divchunk=kw.get("divchunk", 0), divmult=kw.get("divmult", 1.0), sections=kw.get("sections", 0), switch_t=kw.get("switch_t", 0))
+              hardsoft=kw.get("hs", 0), stride=kw.get("stride", 1), cap=kw.get("cap", 0), twin=kw.get("twin", 0), filt=kw.get("filt", 0), divchunk=kw.get("divchunk", 0), divmult=kw.get("divmult", 1.0), sections=kw.get("sections", 0), switch_t=kw.get("switch_t", 0), gpu_round=kw.get("gpu_round", 0))
     out = Out()
     _g["L"].lab_pass(C.byref(cfg), ob.view(np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)), orc._dp(sv), sv.size, orc._dp(tv), tv.size,
                      C.c_double(v0), C.c_double(a0), orc._dp(di), *[C.c_double(x) for x in _g["tun"]], None, C.byref(out))

@@ -476,6 +476,7 @@ struct SolveArgs {
     // Guided bounding pass (round 3): for episodes whose unobstructed optimum -- looked up in a table the host builds per parameter set: the
     // optimal step sequence of the obstacle-free problem from every lattice state (speed, speed one step earlier) -- meets no vehicle, the first
     // bounding attempt only expands cells within tube_w of that path.  The guide only centres the search: a poor one costs a short wasted pass.
+    int tube_dense;        // the guided attempt of the standard first window runs as tube_pass (lane = cell) instead of dp_pass under a tube
     const u16 *guide;      // [N][H] guide cells per layer written by k_predict ([0] = 0xffff: no usable guide), or null = off
     int tube_w;
     int prio_mode;         // (experiment: which estimate prio_thr is compared with)
@@ -1234,6 +1235,169 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     return 0;
 }
 
+// Guided bounding attempt of a four-wave workgroup, dense: lane j of the workgroup IS cell (guide cell of the layer) - tube_w + j.  The tube around the
+// unobstructed optimum holds 2 * tube_w + 1 <= 256 cells per layer, nearly all of them reached, so the general pass's machinery -- compacting the
+// reached cells into a list, rounds of sources, the interval bookkeeping of an in-place window -- buys nothing here and costs most of the pass's
+// instructions.  Two 256-cell layers ping-pong in LDS, every lane relaxes its own cell into the next layer with the same arithmetic, filters and
+// packed (single-precision cost, history) cells as dp_pass<PASS_BOUND> under a tube, and a layer costs two barriers.  Any complete path is a valid
+// bound; what this pass must share with the general one is the reference's one-history-per-cell competition inside the tube, which is what makes
+// its bound the reference's own cost in most episodes.
+// cells: [2][256] u64, penf: [256] float (LDS).  sh.path holds the guide.  Returns true with out.best_bits / out.nodes set if a complete path was found.
+template <bool FASTDIV, bool S1GEN>
+__device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cells, float *penf, PassOut &out) {
+    typedef Mem<true> M;
+    const DevP &p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, S = ep.S, e = ep.e, w = a.tube_w, TW = 2 * w + 1;
+    const double start_s = ep.start_s, delta = ep.delta, dt = p.dt;
+    const double r_dt = ep.r_dt, r_delta = ep.r_delta, zl_dt = a.zl_dt;
+    const bool s1_plain = ep.s1_plain;
+    auto sval = [&](int n) -> double {
+        double v = start_s + (double)n * delta;
+        if constexpr (S1GEN) { if (!s1_plain) { if (n == 1) v = ep.s1; } }
+        return v;
+    };
+    const double kv = p.v_w / p.dt2, ka = p.a_w / (p.dt2 * p.dt2), kj = p.j_w / (p.dt3 * p.dt3), K = kv + ka + kj, invK = 1.0 / K;
+    const bool quad = K > 0.0 && invK < 1e300;
+    const float Kf = (float)K, stepf = (float)delta;
+    const float bandf = (float)a.band;
+    const double rad = quad ? (double)__builtin_sqrtf((float)(a.band * invK)) : 0.0;       // (the band is constant here: a tube layer never exceeds band_cap nodes)
+    u64 *cur = cells, *nxt = cells + 256;
+    M::barrier();                        // previous users of the arrays are done
+    M::st64(&cur[tid], (tid == w) ? 0ull : INF_BITS);          // layer 0: cell 0 (the guide's cell of layer 0) at cost 0, no history
+    if (tid == 0) sh.nlist = 0;
+    u64 lmin = 0ull;
+    int wn = 0;
+    bool complete = true;
+    for (int t = 0; t < H - 1; ++t) {
+        const int base = sh.path[t] - w, base1 = sh.path[t + 1] - w;
+        // ---- next layer: my cell's penalty, "not reached"
+        {
+            const int n1 = base1 + tid;
+            float pf = -1.0f;
+            if (tid < TW && n1 >= 0 && n1 < S) {
+                const size_t row = (size_t)e * H + (t + 1);
+                int nact = a.tab.nact[row];
+                const double *cedge = a.tab.edge + row * a.Kmax * 2;
+                const int *cwin = a.tab.win + row * a.Kmax * 2;
+                const double sn = sval(n1);
+                double d = 1e10;
+                bool blocked = false;
+                for (int c0 = 0; c0 < nact; c0 += 4) {           // (rows in groups of four, loads first; a row taken twice changes nothing)
+                    double vf[4], vb[4]; int w0[4], w1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u < nact ? c0 + u : nact - 1;
+                        vf[u] = cedge[2 * c]; vb[u] = cedge[2 * c + 1]; w0[u] = cwin[2 * c]; w1[u] = cwin[2 * c + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        d = __builtin_fmin(d, fabs(sn - vf[u]));
+                        d = __builtin_fmin(d, fabs(sn - vb[u]));
+                        blocked |= (n1 >= w0[u]) & (n1 < w1[u]);
+                    }
+                }
+                if (!blocked && !(d < p.min_allowed)) pf = (float)p.d_w * __builtin_amdgcn_rcpf((float)d);     // (the penalty zone counts as blocked in this attempt)
+            }
+            __hip_atomic_store(&penf[tid], pf, __ATOMIC_RELAXED, M::SCOPE);
+            M::st64(&nxt[tid], INF_BITS);
+        }
+        M::barrier();                    // A: the next layer is initialised (and everyone is past the previous layer's candidates)
+        // ---- my cell of layer t
+        u64 my_min = ~0ull;
+        {
+            const int i = base + tid;
+            const u64 cb = M::ld64(&cur[tid]);
+            const float Cf = __uint_as_float((unsigned)(cb >> 32));
+            const float lim = __uint_as_float((unsigned)(lmin >> 32)) + bandf;
+            const bool act = tid < TW && cb < INF_BITS && Cf <= lim;
+            wn += __popcll(__ballot(act));
+            int lo = 0, hi = 0;
+            double q_smin = 0.0; float q_base = 0.0f;
+            unsigned key = 0u;
+            if (act) {
+                const unsigned h = (unsigned)cb;
+                const double sv = sval(i);
+                double p1, p2;
+                if (t == 0) { p1 = ep.est_prev; p2 = ep.est_second; }
+                else {
+                    const int pr = (int)(h >> 16), pp = (int)(h & 0xFFFFu);
+                    p1 = sval(pr);
+                    p2 = (t == 1) ? ep.est_prev : sval(pp);
+                    key = ((unsigned)i << 16) | (unsigned)pr;
+                }
+                // st_cy.pyx:65-93, as in dp_pass
+                const double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
+                const double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
+                const double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
+                const double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
+                const double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
+                const double min_v = dmax_py(v + min_a * dt, 0.0);
+                const double max_v = dmin_py(v + max_a * dt, p.v_max);
+                const double min_s = sv + min_v * dt, max_s = sv + max_v * dt;
+                const double x = divc<FASTDIV>(min_s - start_s, delta, r_delta);
+                int mi = (int)x;
+                const int ma = (int)divc<FASTDIV>(max_s - start_s, delta, r_delta);
+                if (mi < x) mi += 1;
+                lo = mi; hi = ma + 1;
+                if (hi > S) hi = S;
+                if (lo < i) lo = i;
+                if (quad && hi > lo) {
+                    const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
+                    const double smin_ = (kv * c_v + ka * c_a + kj * c_j) * invK;
+                    q_smin = smin_;
+                    q_base = Cf + (float)(kv * (c_v - smin_) * (c_v - smin_) + ka * (c_a - smin_) * (c_a - smin_) + kj * (c_j - smin_) * (c_j - smin_));
+                    const double fl = ceil((smin_ - rad - start_s) * r_delta);
+                    const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
+                    const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
+                    const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                    if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
+                    else if (nlo_ >= hi) { lo = hi - 1; }
+                    else { hi = lo + 1; }
+                } else { q_smin = sv; q_base = Cf; }
+                lo = lo > base1 ? lo : base1; hi = hi < base1 + TW ? hi : base1 + TW;      // the next layer's tube
+                if (lo >= hi) { lo = 0; hi = 0; }
+            }
+            float dcur = (hi > lo) ? (float)(sval(lo) - q_smin) : 0.0f;
+            const u64 keyw = (u64)key;
+            for (int k = 0; __ballot(lo + k < hi) != 0ull; k += 4) {
+                float pn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pn[u] = __hip_atomic_load(&penf[(lo + k + u - base1) & 255], __ATOMIC_RELAXED, M::SCOPE);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = lo + k + u;
+                    const float dd = dcur + (float)u * stepf;
+                    const float tot = __builtin_fmaf(Kf * dd, dd, q_base) + pn[u];
+                    if ((n < hi) & (pn[u] >= 0.0f)) {
+                        const u64 val = ((u64)__float_as_uint(tot) << 32) | keyw;
+                        my_min = val < my_min ? val : my_min;
+                        (void)M::min64(&nxt[n - base1], val);
+                    }
+                }
+                dcur += 4.0f * stepf;
+            }
+        }
+        int dummy = 0;
+        wave_min_key(my_min, dummy);
+        if (lane == 0) sh.min_tot[wave] = my_min;
+        M::barrier();                    // B: every offer of this layer is in
+        u64 mt = sh.min_tot[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const u64 m_ = sh.min_tot[k]; mt = m_ < mt ? m_ : mt; }
+        if (mt >= INF_BITS) { complete = false; break; }          // nothing reached the next layer (workgroup-uniform)
+        lmin = mt;
+        u64 *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (lane == 0) atomicAdd(&sh.nlist, wn);
+    M::barrier();
+    out.nodes = sh.nlist;
+    out.best_t = complete ? H - 1 : 0;
+    if (complete) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * 1.00002);
+    M::barrier();                        // (sh.nlist, the arrays: free for the next user)
+    return complete;
+}
+
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
@@ -1310,7 +1474,16 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 __syncthreads();
                 guided = sh.path[0] != 0xffff;
             }
-            for (int att = guided ? -1 : 0; att < 2; ++att) {
+            if constexpr (USE_LDS && NWX == 4) {
+                // (the standard first window: four waves = 256 lanes, one per cell of the tube)
+                if (guided && a.tube_dense && 2 * a.tube_w + 1 <= 256) {
+                    const bool found = tube_pass<FASTDIV, S1GEN>(a, ep, sh, cost, (float *)pen, out);
+                    bn += out.nodes;
+                    if (found) { ubits = out.best_bits; if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_GUIDED], 1u); }
+                    guided = false;
+                }
+            }
+            for (int att = guided ? -1 : 0; att < 2 && ubits == INF_BITS; ++att) {
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN, 0, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
                                                                                    att <= 0 ? a.band : a.band * a.band2_mult, att <= 0, out, 0, att < 0 ? a.tube_w : 0);
                 bn += out.nodes;
