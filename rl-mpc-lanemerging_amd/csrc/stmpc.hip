@@ -682,8 +682,8 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.gsh_max = c->gsh_max;
     a.zl_dt = c->fd2_zl[0]; a.zl_dt2 = c->fd2_zl[1]; a.zl_dt3 = c->fd2_zl[2];
 #ifdef STMPC_PHASE_PROF
-    if ((rc = c->phase_prof.ensure(2 * STMPC_NPH * sizeof(unsigned long long)))) return rc;
-    HIPCHK(hipMemsetAsync(c->phase_prof.p, 0, 2 * STMPC_NPH * sizeof(unsigned long long), st));
+    if ((rc = c->phase_prof.ensure(4 * STMPC_NPH * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipMemsetAsync(c->phase_prof.p, 0, 4 * STMPC_NPH * sizeof(unsigned long long), st));
     a.phase_prof = c->phase_prof.as<unsigned long long>();
 #endif
     a.ckpt = resume ? c->ckpt.as<unsigned char>() : nullptr; a.ckpt_stride = ckpt_stride; a.resume_t = resume_t;
@@ -831,10 +831,10 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         HIPCHK(hipEventElapsedTime(&ms_dp, c->ev1, c->ev2));
 #ifdef STMPC_PHASE_PROF
         if (const char *f = getenv("STMPC_PHASE_DUMP")) {
-            unsigned long long pp[2 * STMPC_NPH];
+            unsigned long long pp[4 * STMPC_NPH];
             HIPCHK(hipMemcpy(pp, c->phase_prof.p, sizeof pp, hipMemcpyDeviceToHost));
             FILE *fp = fopen(f, "w");
-            if (fp) { for (int m = 0; m < 2; ++m) { for (int k = 0; k < STMPC_NPH; ++k) fprintf(fp, "%llu ", pp[m * STMPC_NPH + k]); fprintf(fp, "\n"); } fclose(fp); }
+            if (fp) { for (int m = 0; m < 4; ++m) { for (int k = 0; k < STMPC_NPH; ++k) fprintf(fp, "%llu ", pp[m * STMPC_NPH + k]); fprintf(fp, "\n"); } fclose(fp); }
         }
 #endif
         c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window

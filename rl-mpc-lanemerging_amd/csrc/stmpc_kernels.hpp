@@ -41,10 +41,20 @@ typedef unsigned short u16;
 // the totals to SolveArgs::phase_prof[pass][phase] when the pass ends.  Compiled out of the product build.
 #ifdef STMPC_PHASE_PROF
 #define STMPC_NPH 16
-#define STMPC_PH_DECL unsigned long long ph_acc_[STMPC_NPH] = {0}; unsigned long long ph_t_ = __builtin_readcyclecounter(); unsigned long long ph_cand_ = 0, ph_slots_ = 0;
+#define STMPC_PH_DECL unsigned long long ph_acc_[STMPC_NPH] = {0}; unsigned long long ph_t_ = __builtin_readcyclecounter(); unsigned long long ph_cand_ = 0, ph_slots_ = 0; \
+                      unsigned long long bw_acc_[8] = {0}; const unsigned long long bw_t0_ = __builtin_readcyclecounter();
+// rows 2 + pass of phase_prof: what lane 0 of EVERY wave waited at the barrier with this id (0 S1, 1 B1, 2 B2, 3 B3, 4 B4, 5 S2), slot 15 = the waves' total time
+#define STMPC_BARW(id) do { const unsigned long long b0_ = __builtin_readcyclecounter(); M::barrier(); if ((threadIdx.x & 63) == 0) bw_acc_[id] += __builtin_readcyclecounter() - b0_; } while (0)
 #define STMPC_PH(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc_[k] += n_ - ph_t_; ph_t_ = n_; } } while (0)
-#define STMPC_PH_FLUSH(mode) do { if (threadIdx.x == 0 && a.phase_prof) for (int k_ = 0; k_ < 14; ++k_) atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + k_], ph_acc_[k_]); \
-                                   if ((threadIdx.x & 63) == 0 && a.phase_prof) { atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 14], ph_cand_); atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 15], ph_slots_); } } while (0)
+#ifndef STMPC_PHASE_TIER
+#define STMPC_PHASE_TIER -1     /* >= 0: only this tier's passes are accumulated */
+#endif
+#define STMPC_PH_COUNT(k) do { if (threadIdx.x == 0) ph_acc_[k] += 1ull; } while (0)      /* slots 12 / 13: rounds, candidate batches */
+#define STMPC_PH_FLUSH(mode) do { if (STMPC_PHASE_TIER >= 0 && a.tier != STMPC_PHASE_TIER) break; \
+                                   if (threadIdx.x == 0 && a.phase_prof) for (int k_ = 0; k_ < 14; ++k_) atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + k_], ph_acc_[k_]); \
+                                   if ((threadIdx.x & 63) == 0 && a.phase_prof) { atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 14], ph_cand_); atomicAdd(&a.phase_prof[(mode) * STMPC_NPH + 15], ph_slots_); \
+                                       for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&a.phase_prof[(2 + (mode)) * STMPC_NPH + k_], bw_acc_[k_]); \
+                                       atomicAdd(&a.phase_prof[(2 + (mode)) * STMPC_NPH + 15], __builtin_readcyclecounter() - bw_t0_); } } while (0)
 // slots 14 / 15 of a pass: candidate evaluations that were offered to a cell / lane-slots the waves executed (64 per slot)
 #define STMPC_PH_CAND(okflag) do { ph_cand_ += (unsigned long long)__popcll(__ballot(okflag)); ph_slots_ += 64ull; } while (0)
 #else
@@ -52,6 +62,8 @@ typedef unsigned short u16;
 #define STMPC_PH(k) do { } while (0)
 #define STMPC_PH_FLUSH(mode) do { } while (0)
 #define STMPC_PH_CAND(okflag) do { } while (0)
+#define STMPC_PH_COUNT(k) do { } while (0)
+#define STMPC_BARW(id) M::barrier()
 #endif
 
 namespace stmpc {
@@ -558,6 +570,15 @@ struct WgShared {
 
 enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 
+// Reset of a set of workgroup-wide round figures (min lo, max hi, max fan).  The constants are made opaque where they are used: left to itself
+// the compiler materialises the triple once per kernel, runs out of registers, and reloads it from SCRATCH in front of every reset -- a global
+// memory round trip for the one wave every other wave then waits for at the next barrier.
+__device__ __forceinline__ void agg_reset(int *g) {
+    int big = 0x7fffffff, zero = 0;
+    asm volatile("" : "+v"(big), "+v"(zero));
+    g[0] = big; g[1] = zero; g[2] = zero;
+}
+
 // One forward sweep over the layers by one WORKGROUP of NW wavefronts.  Returns 0 ok, 1 window overflow
 // (workgroup-uniform).
 //
@@ -672,7 +693,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         ckpt_load<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
         if (tid == 0) sh.flags = fl;
     } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
-    if (tid == 0) { sh.agg[0] = 0x7fffffff; sh.agg[1] = 0; sh.agg[2] = 0; sh.agg[4] = 0x7fffffff; sh.agg[5] = 0; sh.agg[6] = 0; }
+    if (tid == 0) { agg_reset(&sh.agg[0]); agg_reset(&sh.agg[4]); }
     M::barrier();
     out.best_t = 0; out.best_n = 0; out.best_bits = 0ull; out.pruned = false; out.nodes = 0; out.maxspan = 0;
     u64 lmin = 0ull;               // cheapest node of the layer being expanded (PASS_BOUND)
@@ -838,7 +859,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if constexpr (MODE == PASS_EXACT) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
             }
         }
-        M::barrier();        // S1
+        STMPC_BARW(0);       // S1
         STMPC_PH(2);                    // 2: scan + S1
         int segbase[SH::waves + 1];
         segbase[0] = 0;
@@ -1007,6 +1028,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
             if constexpr (MODE == PASS_EXACT) { if (__ballot(cut_l) && lane == 0) atomicOr(&sh.flags, 1); }
             STMPC_PH(4);                // 4: source load, range, candidate filter
+            STMPC_PH_COUNT(12);
             if (relax) {
                 const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
                 const int fan_w = wave_max_i(hi - lo);
@@ -1015,7 +1037,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     atomicMin(&sh.agg[ab + 0], clo_w); atomicMax(&sh.agg[ab + 1], chi_w); atomicMax(&sh.agg[ab + 2], fan_w);
                 }
             }
-            M::barrier();     // B1: the round's sources are in registers: their cells may now be overwritten
+            STMPC_BARW(1);    // B1: the round's sources are in registers: their cells may now be overwritten
             STMPC_PH(5);                // 5: wave reductions + B1
             // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer -- nearly always all
             // of them, which the workgroup-wide figures show at once; the per-wave walk is the rare fallback.
@@ -1048,7 +1070,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             const int a_k = list_at(rlast);                      // lowest source of this round (uniform)
             if (clo >= chi) {                                 // (keeps sh.red / sh.agg stable until everyone has read them)
                 M::barrier();
-                if (agg_used) { if (tid == 0) { sh.agg[ab + 0] = 0x7fffffff; sh.agg[ab + 1] = 0; sh.agg[ab + 2] = 0; } M::barrier(); }     // (fallback walk that took an empty wave only)
+                if (agg_used) { if (tid == 0) agg_reset(&sh.agg[ab]); M::barrier(); }     // (fallback walk that took an empty wave only)
                 continue;
             }
             const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
@@ -1078,10 +1100,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 if (need_lo < pv_lo) repen(need_lo, pv_lo);
                 if (need_hi > pv_hi) repen(pv_hi, need_hi);
             }
-            M::barrier();     // B2: next-layer cells of this round are initialised
+            STMPC_BARW(2);    // B2: next-layer cells of this round are initialised
             // (everyone has read the workgroup-wide figures; the next round's atomics come after this round's B3 -- the bounding pass has
             // no B3: its next round uses the other set, which was reset a whole round ago)
-            if (agg_used && tid == 0) { sh.agg[ab + 0] = 0x7fffffff; sh.agg[ab + 1] = 0; sh.agg[ab + 2] = 0; }
+            if (agg_used && tid == 0) agg_reset(&sh.agg[ab]);
             STMPC_PH(7);                // 7: cell initialisation (penalties) + B2
 
             auto cand = [&](int slot) -> int { return lo + sub + (slot << gsh); };      // cell of this lane's slot-th candidate
@@ -1123,6 +1145,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             for (int cbase = 0; (cbase << gsh) < fan; cbase += FANMAX) {
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
+                STMPC_PH_COUNT(13);
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
 #ifdef STMPC_UB88
                 constexpr int UB = (NWX == 88) ? STMPC_UB88 : ((FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX));
@@ -1170,7 +1193,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         for (int u = 0; u < UB; ++u) tb[ub + u] = ~0ull;
                     }
                 }
-                M::barrier();     // B3: every min of this round is in
+                STMPC_BARW(3);    // B3: every min of this round is in
                 STMPC_PH(8);            // 8: stage A (candidate costs, atomic minima) + B3
                 // stage B: the unique first setter of a cell's final value records the predecessor.
                 // Read-backs are issued in groups of 4 (unconditionally) so their LDS latencies overlap.
@@ -1185,7 +1208,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(&hist[cand(cbase + ub + u) & WM], key); }
                     }
                 }
-                M::barrier();     // B4
+                STMPC_BARW(4);    // B4
                 STMPC_PH(9);            // 9: stage B (first setter writes the predecessor) + B4
                 if constexpr (MODE == PASS_EXACT) {
                     // stage C: equal total cost -> the smaller predecessor index wins (heap tuple order, st_cy.pyx:388)
@@ -1211,7 +1234,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             int dummy = 0;
             wave_min_key(my_min_tot, dummy);
             if (lane == 0) sh.min_tot[wave] = my_min_tot;
-            M::barrier();    // S2
+            STMPC_BARW(5);   // S2
             u64 mt = ~0ull;
             for (int w = 0; w < NW; ++w) { const u64 m_ = sh.min_tot[w]; mt = m_ < mt ? m_ : mt; }
             lmin = mt;

@@ -76,13 +76,15 @@ def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("tube", ["0", "8", "96", "4000"])
-def test_guided_bounding_attempt_is_exact(tube, restore_settings, monkeypatch):
+@pytest.mark.parametrize("tube,dense", [("0", "1"), ("8", "1"), ("96", "1"), ("96", "0"), ("127", "1"), ("4000", "1")])
+def test_guided_bounding_attempt_is_exact(tube, dense, restore_settings, monkeypatch):
     """The guided bounding attempt (a tube around the unobstructed optimum, guide cells from the predictor kernel) only supplies a bound: whatever
-    the tube's width -- off, too narrow to hold a path, the default, wider than the lattice -- every output bit is the reference's; and on the wide
-    lattice it does supply the bound for a good part of the states."""
+    the tube's width -- off, too narrow to hold a path, the default, the widest the dense pass takes (one lane per cell: 255 cells), wider than the
+    lattice -- and whichever of the two implementations runs it (tube_pass, or dp_pass under a tube), every output bit is the reference's; and on the
+    wide lattice it does supply the bound for a good part of the states."""
     from rl_mpc_lanemerging_amd import _capi, st
     monkeypatch.setenv("STMPC_TUBE", tube)
+    monkeypatch.setenv("STMPC_TUBE_DENSE", dense)
     ctx = _capi.Context(0)
     for fname in STATE_FILES:
         g = load_golden(fname)
