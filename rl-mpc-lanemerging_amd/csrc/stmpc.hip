@@ -155,6 +155,7 @@ struct stmpc_ctx {
     double fd2_dt = 0, fd2_dt2 = 0, fd2_dt3 = 0, fd2_zl[3] = {0, 0, 0}; bool fd2_ok = false;      // fastdiv2_ok results for the current dt
     int prune = -1;               // -1 auto (bounded search only when the fan-out is large), 0 off, 1 on
     double band_override = 0.0;
+    int band_dense = 1;            // STMPC_BAND_DENSE=0/1: dense ordinary bounding attempts (band_pass)
     int tube_dense = 1;            // STMPC_TUBE_DENSE=0/1: dense guided attempt (tube_pass)
     int band_cap = 450;            // STMPC_BAND_CAP: nodes per layer the pre-pass steers its band towards (0 = fixed band); 300 until the pre-pass moved to
                                    // packed single precision (round 3): with candidates at a fifth of their former cost a wider pre-pass pays for itself in
@@ -278,6 +279,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_BAND2_MULT")) { double v = atof(w); if (v >= 1.0) c->band2_mult = v; }
     if (const char *w = getenv("STMPC_STAGE_TAB")) c->allow_stage_tab = atoi(w) != 0;
     if (const char *w = getenv("STMPC_OVERLAP")) c->overlap = atoi(w) != 0 ? 1 : 0;
+    if (const char *w = getenv("STMPC_BAND_DENSE")) c->band_dense = atoi(w) != 0;
     if (const char *w = getenv("STMPC_TUBE_DENSE")) c->tube_dense = atoi(w) != 0;
     if (const char *w = getenv("STMPC_BAND_CAP")) { int v = atoi(w); if (v >= 0) c->band_cap = v; }
     if (const char *w = getenv("STMPC_SPLIT")) c->split = atoi(w) != 0;
@@ -674,7 +676,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     }
     a.band_cap = c->band_cap;
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
-    a.guide = g_cells; a.tube_w = c->tube_w; a.tube_dense = c->tube_dense;
+    a.guide = g_cells; a.tube_w = c->tube_w; a.tube_dense = c->tube_dense; a.band_dense = c->band_dense;
     a.retry_move = resume ? c->retry_move : 0;
     a.prio_thr = c->prio_thr; a.prio_mode = getenv("STMPC_PRIO_MODE") ? atoi(getenv("STMPC_PRIO_MODE")) : 0;
     a.bp_rel8 = bp_rel8 ? 1 : 0;

@@ -488,6 +488,7 @@ struct SolveArgs {
     // Guided bounding pass (round 3): for episodes whose unobstructed optimum -- looked up in a table the host builds per parameter set: the
     // optimal step sequence of the obstacle-free problem from every lattice state (speed, speed one step earlier) -- meets no vehicle, the first
     // bounding attempt only expands cells within tube_w of that path.  The guide only centres the search: a poor one costs a short wasted pass.
+    int band_dense;        // the ordinary bounding attempts of the standard first window run as band_pass (dense windows) before dp_pass is tried
     int tube_dense;        // the guided attempt of the standard first window runs as tube_pass (lane = cell) instead of dp_pass under a tube
     const u16 *guide;      // [N][H] guide cells per layer written by k_predict ([0] = 0xffff: no usable guide), or null = off
     int tube_w;
@@ -1421,6 +1422,205 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
     return complete;
 }
 
+// The ordinary bounding attempts of a four-wave workgroup, dense: the layer being expanded and the layer being built are two windows of
+// STMPC_BAND_W consecutive cells in LDS (ping-pong), lane tid owns cells tid, tid + 256, ... of each, and a layer costs three barriers -- no list
+// of reached cells, no rounds, no interval bookkeeping of an in-place window (dp_pass<PASS_BOUND> pays for those with most of its instructions:
+// the band-limited layers hold a few hundred nodes spread over up to a thousand cells).  Same selection (cost within the band of the layer's
+// cheapest node, the band steered towards band_cap nodes), same per-source range, quadratic filter and packed single-precision candidates as
+// dp_pass, so the bound is the same wherever dp_pass would not have dropped sources; a layer pair that does not fit the window returns 2 and
+// the caller runs the general pass instead.
+// Returns 0: complete path found (out.best_bits / out.nodes), 1: no complete path under this band, 2: window too small.
+#define STMPC_BAND_W 1536
+#define STMPC_BAND_SLOTS (STMPC_BAND_W / 256)
+template <bool FASTDIV, bool S1GEN>
+__device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, unsigned char *lds /* >= 30 KB */, const double band, const bool hardsoft, PassOut &out) {
+    typedef Mem<true> M;
+    const DevP &p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, S = ep.S, e = ep.e;
+    const double start_s = ep.start_s, delta = ep.delta, dt = p.dt;
+    const double r_dt = ep.r_dt, r_delta = ep.r_delta, zl_dt = a.zl_dt;
+    const bool s1_plain = ep.s1_plain;
+    auto sval = [&](int n) -> double {
+        double v = start_s + (double)n * delta;
+        if constexpr (S1GEN) { if (!s1_plain) { if (n == 1) v = ep.s1; } }
+        return v;
+    };
+    const double kv = p.v_w / p.dt2, ka = p.a_w / (p.dt2 * p.dt2), kj = p.j_w / (p.dt3 * p.dt3), K = kv + ka + kj, invK = 1.0 / K;
+    const bool quad = K > 0.0 && invK < 1e300;
+    const float Kf = (float)K, stepf = (float)delta;
+    const int mshift = a.maxshift - 62;          // every target lies below (its source) + mshift (SolveArgs::maxshift carries 66 cells of alignment slack)
+    u64 *cur = (u64 *)lds, *nxt = cur + STMPC_BAND_W;
+    float *penf = (float *)(nxt + STMPC_BAND_W);
+    M::barrier();                        // previous users of the arrays are done
+#pragma unroll 1
+    for (int s_ = 0; s_ < STMPC_BAND_SLOTS; ++s_) M::st64(&cur[s_ * 256 + tid], (s_ == 0 && tid == 0) ? 0ull : INF_BITS);     // layer 0: cell 0 at cost 0
+    int base = 0;
+    u64 lmin = 0ull;
+    double bandt = band;
+    int total_nodes = 0;
+    int rc = 0;
+    M::barrier();
+    for (int t = 0; t < H - 1; ++t) {
+        // ---- which of my cells are expanded; the layer's extent and node count
+        const float lim = __uint_as_float((unsigned)(lmin >> 32)) + (float)bandt;
+        unsigned am = 0u;
+        int my_lo = 0x7fffffff, my_hi = -1, cnt = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < STMPC_BAND_SLOTS; ++s_) {
+            const u64 cb = M::ld64(&cur[s_ * 256 + tid]);
+            const bool act = cb < INF_BITS && __uint_as_float((unsigned)(cb >> 32)) <= lim;
+            if (act) { am |= 1u << s_; const int i = base + s_ * 256 + tid; my_lo = i < my_lo ? i : my_lo; my_hi = i > my_hi ? i : my_hi; }
+            cnt += __popcll(__ballot(act));
+        }
+        my_lo = wave_min_i(my_lo); my_hi = wave_max_i(my_hi);
+        if (lane == 0) { sh.red[wave * 4 + 0] = my_lo; sh.red[wave * 4 + 1] = my_hi; sh.cnt[wave] = cnt; }
+        M::barrier();                    // C
+        int slo = 0x7fffffff, shi = -1, nlist = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int l_ = sh.red[k * 4 + 0], h_ = sh.red[k * 4 + 1]; slo = l_ < slo ? l_ : slo; shi = h_ > shi ? h_ : shi; nlist += sh.cnt[k]; }
+        total_nodes += nlist;
+        if (a.band_cap > 0 && nlist > 0) {                  // (dp_pass's steering of the band)
+            const double f = (double)a.band_cap / (double)nlist;
+            bandt = bandt * (f < 1.0 ? f : sqrt(f));
+            bandt = bandt > band ? band : (bandt < 0.05 * band ? 0.05 * band : bandt);
+        }
+        if (nlist == 0) { rc = 1; break; }
+        int thi = shi + mshift; thi = thi > S ? S : thi;
+        if (thi - slo > STMPC_BAND_W) { rc = 2; break; }    // (workgroup-uniform)
+        const int base1 = slo;
+        const double rad = (double)__builtin_sqrtf((float)(bandt * invK));
+        // ---- next layer: "not reached" everywhere, penalties where a target can land
+        {
+            const size_t row = (size_t)e * H + (t + 1);
+            const int nact = a.tab.nact[row];
+            const double *cedge = a.tab.edge + row * a.Kmax * 2;
+            const int *cwin = a.tab.win + row * a.Kmax * 2;
+#pragma unroll 1
+            for (int s_ = 0; s_ < STMPC_BAND_SLOTS; ++s_) {
+                const int j = s_ * 256 + tid, n1 = base1 + j;
+                M::st64(&nxt[j], INF_BITS);
+                if (n1 < thi) {
+                    const double sn = sval(n1);
+                    double d = 1e10;
+                    bool blocked = false;
+                    for (int c0 = 0; c0 < nact; c0 += 4) {       // (rows in groups of four, loads first; a row taken twice changes nothing)
+                        double vf[4], vb[4]; int w0[4], w1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = c0 + u < nact ? c0 + u : nact - 1;
+                            vf[u] = cedge[2 * c]; vb[u] = cedge[2 * c + 1]; w0[u] = cwin[2 * c]; w1[u] = cwin[2 * c + 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            d = __builtin_fmin(d, fabs(sn - vf[u]));
+                            d = __builtin_fmin(d, fabs(sn - vb[u]));
+                            blocked |= (n1 >= w0[u]) & (n1 < w1[u]);
+                        }
+                    }
+                    const bool close = d < p.min_allowed;
+                    if (hardsoft && close) blocked = true;
+                    const float den = (float)(close ? dmax_py(d, 1.0) : d);
+                    const float pf = (float)p.d_w * ((close ? 1000000.0f : 1.0f) * __builtin_amdgcn_rcpf(den));
+                    __hip_atomic_store(&penf[j], blocked ? -1.0f : pf, __ATOMIC_RELAXED, M::SCOPE);
+                }
+            }
+        }
+        M::barrier();                    // A: the next layer is initialised
+        // ---- my cells of layer t
+        u64 my_min = ~0ull;
+#pragma unroll 1
+        for (int s_ = 0; s_ < STMPC_BAND_SLOTS; ++s_) {
+            const bool act = (am >> s_) & 1u;
+            if (__ballot(act) == 0ull) continue;
+            const int i = base + s_ * 256 + tid;
+            int lo = 0, hi = 0;
+            double q_smin = 0.0; float q_base = 0.0f;
+            unsigned key = 0u;
+            if (act) {
+                const u64 cb = M::ld64(&cur[s_ * 256 + tid]);
+                const float Cf = __uint_as_float((unsigned)(cb >> 32));
+                const unsigned h = (unsigned)cb;
+                const double sv = sval(i);
+                double p1, p2;
+                if (t == 0) { p1 = ep.est_prev; p2 = ep.est_second; }
+                else {
+                    const int pr = (int)(h >> 16), pp = (int)(h & 0xFFFFu);
+                    p1 = sval(pr);
+                    p2 = (t == 1) ? ep.est_prev : sval(pp);
+                    key = ((unsigned)i << 16) | (unsigned)pr;
+                }
+                // st_cy.pyx:65-93, as in dp_pass
+                const double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
+                const double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
+                const double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
+                const double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
+                const double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
+                const double min_v = dmax_py(v + min_a * dt, 0.0);
+                const double max_v = dmin_py(v + max_a * dt, p.v_max);
+                const double min_s = sv + min_v * dt, max_s = sv + max_v * dt;
+                const double x = divc<FASTDIV>(min_s - start_s, delta, r_delta);
+                int mi = (int)x;
+                const int ma = (int)divc<FASTDIV>(max_s - start_s, delta, r_delta);
+                if (mi < x) mi += 1;
+                lo = mi; hi = ma + 1;
+                if (hi > S) hi = S;
+                if (lo < i) lo = i;
+                if (quad && hi > lo) {
+                    const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
+                    const double smin_ = (kv * c_v + ka * c_a + kj * c_j) * invK;
+                    q_smin = smin_;
+                    q_base = Cf + (float)(kv * (c_v - smin_) * (c_v - smin_) + ka * (c_a - smin_) * (c_a - smin_) + kj * (c_j - smin_) * (c_j - smin_));
+                    const double fl = ceil((smin_ - rad - start_s) * r_delta);
+                    const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
+                    const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
+                    const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                    if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
+                    else if (nlo_ >= hi) { lo = hi - 1; }
+                    else { hi = lo + 1; }
+                } else { q_smin = sv; q_base = Cf; }
+                if (hi > thi) hi = thi;              // (cannot happen: thi bounds every target; keeps the window safe)
+                if (lo >= hi) { lo = 0; hi = 0; }
+            }
+            float dcur = (hi > lo) ? (float)(sval(lo) - q_smin) : 0.0f;
+            const u64 keyw = (u64)key;
+            for (int k = 0; __ballot(lo + k < hi) != 0ull; k += 4) {
+                float pn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { int jx = lo + k + u - base1; jx = jx < 0 ? 0 : (jx >= STMPC_BAND_W ? STMPC_BAND_W - 1 : jx); pn[u] = __hip_atomic_load(&penf[jx], __ATOMIC_RELAXED, M::SCOPE); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = lo + k + u;
+                    const float dd = dcur + (float)u * stepf;
+                    const float tot = __builtin_fmaf(Kf * dd, dd, q_base) + pn[u];
+                    if ((n < hi) & (pn[u] >= 0.0f)) {
+                        const u64 val = ((u64)__float_as_uint(tot) << 32) | keyw;
+                        my_min = val < my_min ? val : my_min;
+                        (void)M::min64(&nxt[n - base1], val);
+                    }
+                }
+                dcur += 4.0f * stepf;
+            }
+        }
+        int dummy = 0;
+        wave_min_key(my_min, dummy);
+        if (lane == 0) sh.min_tot[wave] = my_min;
+        M::barrier();                    // B: every offer of this layer is in
+        u64 mt = sh.min_tot[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const u64 m_ = sh.min_tot[k]; mt = m_ < mt ? m_ : mt; }
+        if (mt >= INF_BITS) { rc = 1; break; }              // nothing reached the next layer
+        lmin = mt;
+        u64 *tmp = cur; cur = nxt; nxt = tmp;
+        base = base1;
+    }
+    out.nodes = total_nodes;
+    out.best_t = rc == 0 ? H - 1 : 0;
+    if (rc == 0) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * 1.00002);
+    M::barrier();                        // the arrays are free for the next user
+    return rc;
+}
+
 // Solve one episode with one workgroup.  Returns 0 ok, 1 window overflow (workgroup-uniform).
 template <bool USE_LDS, bool GRID, bool FASTDIV, int KT, int FANMAX, bool S1GEN, int RES = 0, int NWX = STMPC_MAXWAVES>
 __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, u64 *cost, unsigned *hist,
@@ -1507,6 +1707,15 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 }
             }
             for (int att = guided ? -1 : 0; att < 2 && ubits == INF_BITS; ++att) {
+                if constexpr (USE_LDS && NWX == 4) {
+                    if (att >= 0 && a.band_dense) {
+                        const int rb = band_pass<FASTDIV, S1GEN>(a, ep, sh, (unsigned char *)cost, att == 0 ? a.band : a.band * a.band2_mult, att == 0, out);
+                        bn += out.nodes;
+                        if (rb == 0) { ubits = out.best_bits; break; }
+                        if (rb == 1) continue;             // no complete path under this band: next attempt
+                        // (rb == 2: the layers do not fit the dense window: the general pass takes this attempt)
+                    }
+                }
                 rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_BOUND, FANMAX, S1GEN, 0, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, INF_BITS,
                                                                                    att <= 0 ? a.band : a.band * a.band2_mult, att <= 0, out, 0, att < 0 ? a.tube_w : 0);
                 bn += out.nodes;

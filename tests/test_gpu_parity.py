@@ -57,7 +57,7 @@ def test_batch_matches_reference_golden(fname, gpu_ctx, restore_settings):
         assert np.array_equal(seq, g["s_sequence"][i])
 
 
-@pytest.mark.parametrize("prune,band", [("0", "0"), ("1", "0"), ("1", "3"), ("1", "100000"), ("2", "0")])
+@pytest.mark.parametrize("prune,band", [("0", "0"), ("1", "0"), ("1", "3"), ("1", "100000"), ("2", "0"), ("1", "nodense")])
 def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
     """The banded pre-pass + bounded exact pass returns the same bits as the unbounded DP, whatever the band
     (a tiny band makes the bound loose or absent, a huge one makes the pre-pass the full search)."""
@@ -65,7 +65,9 @@ def test_bounded_search_is_exact(prune, band, restore_settings, monkeypatch):
     monkeypatch.setenv("STMPC_PRUNE", "1" if prune == "2" else prune)
     if prune == "2":
         monkeypatch.setenv("STMPC_TWO_PHASE", "1")      # bound-only phase, heaviest-first order, exact phase
-    if band != "0":
+    if band == "nodense":
+        monkeypatch.setenv("STMPC_BAND_DENSE", "0")      # the general pass (dp_pass) runs the bounding attempts instead of the dense one (band_pass)
+    elif band != "0":
         monkeypatch.setenv("STMPC_BAND", band)
     ctx = _capi.Context(0)
     for fname in STATE_FILES:
