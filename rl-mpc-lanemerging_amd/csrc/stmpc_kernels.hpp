@@ -1697,8 +1697,9 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 __syncthreads();
                 guided = sh.path[0] != 0xffff;
             }
-            if constexpr (USE_LDS && NWX == 4) {
-                // (the standard first window: four waves = 256 lanes, one per cell of the tube)
+            if constexpr (USE_LDS && NWX == 4 && FANMAX != 9) {
+                // (the standard first window: four waves = 256 lanes, one per cell of the tube; not compiled into the narrow-lattice kernels, whose
+                // search is not bounded by default and whose register allocation has no room to spare)
                 if (guided && a.tube_dense && 2 * a.tube_w + 1 <= 256) {
                     const bool found = tube_pass<FASTDIV, S1GEN>(a, ep, sh, cost, (float *)pen, out);
                     bn += out.nodes;
@@ -1707,7 +1708,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
                 }
             }
             for (int att = guided ? -1 : 0; att < 2 && ubits == INF_BITS; ++att) {
-                if constexpr (USE_LDS && NWX == 4) {
+                if constexpr (USE_LDS && NWX == 4 && FANMAX != 9) {
                     if (att >= 0 && a.band_dense) {
                         const int rb = band_pass<FASTDIV, S1GEN>(a, ep, sh, (unsigned char *)cost, att == 0 ? a.band : a.band * a.band2_mult, att == 0, out);
                         bn += out.nodes;
