@@ -69,3 +69,43 @@ for nm,k in (("bn",bn.astype(float)),("span",span.astype(float)),("bn*span",bn*s
         print("   + reserve R=%2d      : tier0 end %.0f, tier1 end %.0f (median start %.0f)"%((R,)+sim(k,R,heavy=heavy)))
 print("overflow predicted by span>600: recall %.2f precision %.2f (n=%d)"%((span[hasC]>600).mean(),hasC[span>600].mean(),(span>600).sum()))
 print("overflow predicted by bn>9000: recall %.2f precision %.2f (n=%d)"%((bn[hasC]>9000).mean(),hasC[bn>9000].mean(),(bn>9000).sum()))
+
+# ---- exact-task order combined with units handed over to the second window while the first launch runs (K units stop taking tasks once fewer
+# than left_thr tasks are left): replayed with oracle knowledge of the overflows and with what the bounding pass knows
+span=(t[:,12]&0xffffffff).astype(np.int64); bn=(t[:,12]>>32).astype(np.int64)
+def sim2(key, K=0, left_thr=0, ncu=256, lat=60.0):
+    xs=[e for e in np.argsort(-key,kind='stable') if hasB[e]]
+    tasks=[('b',e) for e in range(N)]+[('x',e) for e in xs]
+    nt=len(tasks); nxt=0
+    free=[(0.0,s) for s in range(ncu*4)]; heapq.heapify(free)
+    bdone=np.zeros(N); disc=np.full(N,np.inf); slot_end=np.zeros(ncu*4)
+    while nxt<nt:
+        tm,s=heapq.heappop(free)
+        cu=s//4
+        if cu>=ncu-K and (nt-nxt)<left_thr:
+            slot_end[s]=tm; continue
+        kind,e=tasks[nxt]; nxt+=1
+        if kind=='b':
+            bdone[e]=tm+bd[e]; heapq.heappush(free,(bdone[e],s))
+            if hasC[e] and not hasB[e]: disc[e]=bdone[e]
+        else:
+            st=max(tm,bdone[e]); en=st+ed[e]; heapq.heappush(free,(en,s))
+            if hasC[e]: disc[e]=en
+    while free:
+        tm,s=heapq.heappop(free); slot_end[s]=max(slot_end[s],tm)
+    t0end=slot_end.max()
+    cu_free=slot_end.reshape(-1,4).max(axis=1)+lat
+    cus=[(x,i) for i,x in enumerate(cu_free)]; heapq.heapify(cus)
+    pending=set(np.nonzero(hasC)[0].tolist()); t1end=0.0
+    while pending:
+        tm,c=heapq.heappop(cus)
+        avail=[e for e in pending if disc[e]<=tm]
+        if not avail:
+            heapq.heappush(cus,(min(disc[e] for e in pending),c)); continue
+        avail.sort(key=lambda e:(not heavy[e],disc[e]))
+        e=avail[0]; pending.discard(e); t1end=max(t1end,tm+cd[e]); heapq.heappush(cus,(tm+cd[e],c))
+    return t0end,t1end
+print("---- exact-task order + hand-over")
+for nm,key in (("oracle overflow first",hasC*1.0),("oracle heavy-tier1 first",cd),("oracle LPT total",ed+cd),("pred span>600",(span>600)*1.0),("pred span",span.astype(float))):
+    for K,thr in ((0,0),(24,3000),(32,3000),(48,3000),(32,2400)):
+        print("%-26s K=%2d thr=%4d: tier0 end %.0f tier1 end %.0f"%((nm,K,thr)+sim2(key,K,thr)))
