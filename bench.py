@@ -25,7 +25,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak
-MEASURED = os.path.join(REPO, "profiles", "r3", "measured.json")   # counters bench.py cannot regenerate itself (rocprofv3 passes)
+# counters bench.py cannot regenerate itself (rocprofv3 --pmc passes, scripts/profile_gpu.sh + scripts/profile_summarize.py): the newest
+# round's file that exists.  Each workload entry carries the source hash of the library it was taken from ("csrc_hash"); the bench line says
+# "stale": true wherever it quotes such a counter and the running library was built from other sources.
+MEASURED_CANDIDATES = [os.path.join(REPO, "profiles", r, "measured.json") for r in ("r4", "r3")]
+MEASURED = next((m for m in MEASURED_CANDIDATES if os.path.exists(m)), MEASURED_CANDIDATES[0])
 
 
 def parse_args():
@@ -165,6 +169,14 @@ def run(args):
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
+    # a fast-but-wrong build must not look like a result: any parity flag that is false fails the run (the line above says which)
+    par = out.get("parity_vs_oracle") or {}
+    bad = [k for k, v in par.items() if v is False]
+    if out.get("pipelined") and out["pipelined"].get("outputs_identical_across_buffers") is False:
+        bad.append("pipelined.outputs_identical_across_buffers")
+    if bad:
+        sys.stderr.write("bench.py: PARITY FAILURE against the oracle: %s\n" % ", ".join(bad))
+        sys.exit(3)
 
 
 def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, sharding, synth):
@@ -315,6 +327,9 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         measured = json.load(open(MEASURED)).get(args.workload, {})
     except (OSError, ValueError):
         pass
+    lib_hash = _capi.library_source_hash()
+    measured_rel = os.path.relpath(MEASURED, REPO)
+    measured_stale = bool(measured) and measured.get("csrc_hash") != lib_hash      # counters from another build of the kernels
 
     # ---- roofline of the dominant kernel (the LDS lattice-DP kernel), from HIP events on the launch stream
     bytes_per_solve = 140 + 16 + 4 * H        # state in (K=6) + action/cost/best_t + path_idx[H]
@@ -323,7 +338,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
     roofline = {"bound": "hbm", "limiting_unit": "VALU instruction issue + LDS round-trip latency of a branchy fp64 DP (see issue, fp64_valu); HBM is reported because BASELINE.json asks for it",
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured.get("hbm_bytes_per_step"),
-                "traffic_source": measured.get("hbm_source"),
+                "traffic_source": measured.get("hbm_source"), "traffic_stale": measured_stale if measured.get("hbm_bytes_per_step") else None,
                 "kernel": "stmpc::k_solve<true,false,...> (LDS lattice DP; one launch per LDS window tier, summed per step)",
                 "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve, "bytes_per_launch": bytes_per_solve * n,
                 "note": "algorithmic HBM bytes are %d B/solve (SURVEY 8d): the path is fp64-VALU/LDS-latency bound, not HBM bound; "
@@ -343,6 +358,8 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                       "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-spawn" if world > 1 else "single")},
            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
            "rccl_ranks": (dist.get_world_size() if use_dist else 0),
+           "library": {"backend": _capi.backend_info(), "csrc_hash": lib_hash, "measured_counters": measured_rel,
+                       "measured_counters_csrc_hash": measured.get("csrc_hash"), "measured_counters_stale": measured_stale},
            "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
            "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
                      "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]), "guided_bounds": int(tier_stats.get("guided", 0)),
@@ -424,6 +441,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                             "full_layered_dp_frac": full_flops * per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                             "heap_nodes_per_solve": hp["nodes"] / mh, "heap_edges_per_solve": hp["edges"] / mh,
                             "kernel_nodes_per_solve": nodes_exec, "kernel_candidates_per_node": cand_per_node,
+                            "kernel_candidates_per_node_stale": measured_stale if cand_per_node else None,
                             "note": "flops = 27/edge + 26/node (+6*K per touched cell for the full DP) + 40*K*H for the predictor (SURVEY 8d); "
                                     "reference_algorithm_* prices the heap Dijkstra's own node/edge counts, which is the useful work"}
         # the unit that is actually half-busy: instruction issue.  Wave-instructions per step from the committed counter pass (same command,
@@ -433,7 +451,9 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
             out["issue"] = {"valu_wave_instructions_per_step": vi, "salu_wave_instructions_per_step": si,
                             "valu_issue_slots_per_step": 1024 * dp_ms * 1e-3 * 2.4e9 / 4.0,
                             "valu_busy_frac": vi * 4.0 / (1024 * dp_ms * 1e-3 * 2.4e9),
-                            "source": "profiles/r3/measured.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., scripts/profile_gpu.sh), kernel time of this run"}
+                            "stale": measured_stale,
+                            "source": "%s (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., scripts/profile_gpu.sh; taken from library sources %s), kernel time of this run"
+                                      % (measured_rel, measured.get("csrc_hash"))}
     return out
 
 

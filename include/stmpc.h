@@ -27,7 +27,10 @@
  *
  * Concurrency: a context owns one set of scratch buffers, work counters and overflow queues; AT MOST ONE batched call may be
  * in flight per context (calls on one stream are naturally ordered; calls on different streams, or from different host
- * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only.
+ * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only -- with one exception: the first
+ * wide-lattice solve after a change of the dynamics or cost parameters rebuilds a small table on the host (a few ms) and waits for the
+ * device once (hipDeviceSynchronize) before replacing the previous one; calls with unchanged parameters never synchronise.
+ * Environment knobs (STMPC_*) are read once, in stmpc_create.
  * Scratch: the wide-lattice solver keeps one back-pointer per lattice cell of the first window and time layer per episode when it may continue
  * an overflowing search in the next window -- one byte (the distance to the predecessor) when no step of the dynamics exceeds 255 cells, else
  * two: N * H * 2048 B = 0.33 GB for 4096 episodes at H = 40, 0.66 GB for 8192, released by stmpc_destroy -- plus a 24 KB checkpoint slot per

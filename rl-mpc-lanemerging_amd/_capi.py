@@ -209,6 +209,12 @@ def backend_info():
     return load().stmpc_backend_info().decode()
 
 
+def library_source_hash():
+    """sha256[:16] of the sources the loaded library was built from (``build.source_hash`` at build time), or "unknown"."""
+    info = backend_info()
+    return info.rsplit("src=", 1)[1].strip() if "src=" in info else "unknown"
+
+
 class Context:
     """One HIP device + its scratch (``stmpc_ctx``)."""
 

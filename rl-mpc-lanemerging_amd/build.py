@@ -27,6 +27,20 @@ def find_hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+def source_hash():
+    """sha256[:16] over the library's sources (csrc/* and include/stmpc.h, by name).  Compiled into the library
+    (``stmpc_backend_info`` ends with ``src=<hash>``) and stamped into profiles/*/measured.json, so that counters
+    taken from another build of the kernels are recognisable as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    files.append(os.path.join(REPO_ROOT, "include", "stmpc.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -39,7 +53,7 @@ def build(force=False, verbose=False):
     """Compile csrc/stmpc.hip for gfx950 into ``libstmpc.so`` next to this file."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(REPO_ROOT, "include"),
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-DSTMPC_SRC_HASH="%s"' % source_hash(), "-I" + os.path.join(REPO_ROOT, "include"),
                                          os.path.join(CSRC, "stmpc.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -179,9 +179,12 @@ struct stmpc_ctx {
     int cu_reserve = 0;
     int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
     std::vector<unsigned char> guide_host;
-    DevBuf guide_tab, guide_cells; double guide_key[12] = {0}; int guide_imax = 0, guide_D = 0, guide_H = 0; bool guide_ok = false;
+    DevBuf guide_tab, guide_cells; double guide_key[12] = {0}; int guide_imax = 0, guide_D = 0, guide_H = 0; bool guide_ok = false, guide_key_valid = false;
     int prio_thr = 32000;          // STMPC_PRIO=t (0 = off): an overflowing search with more than t (layers left x nodes of the saved layer) ahead of it is served first
                                    // by the second window (SolveArgs::prio_thr): 4.60 -> 4.46 ms over 12 seeds at N = 4096, flat from 25000 to 35000
+    int prio_mode = 0;             // STMPC_PRIO_MODE (experiment: which estimate prio_thr is compared with)
+    bool bp16 = false;             // STMPC_BP16=1: two-byte back-pointers even where one byte would do
+    size_t resume_refused_for = 0; // back-pointer bytes of the last request the quarter-of-free-memory rule turned down (not asked again until the request changes)
     int retry_move = 0;            // STMPC_RETRY_MOVE=k: see SolveArgs::retry_move
     double retry_mult[3] = {1.05, 1.3, 4.0};    // STMPC_RETRY="a,b,c": growth of a bound that turned out to be below the reference's terminal cost.  Round 2 grew gently
                                                 // (1.02, 1.08, 1.3): most failures need less than 0.2 %, but the rare search that fails twice is three ever larger passes
@@ -197,20 +200,23 @@ extern "C" {
 
 const char *stmpc_last_error(void) { return g_err.c_str(); }
 
+#ifndef STMPC_SRC_HASH
+#define STMPC_SRC_HASH "unknown"      /* build.py passes sha256[:16] of csrc/ + include/stmpc.h */
+#endif
 const char *stmpc_backend_info(void) {
     if (!g_info.empty()) return g_info.c_str();
     int n = 0;
     char buf[512];
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
-        g_info = "stmpc 0.1 hip (no device)";
+        g_info = "stmpc 0.1 hip (no device) src=" STMPC_SRC_HASH;
         return g_info.c_str();
     }
     hipDeviceProp_t pr;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { g_info = "stmpc 0.1 hip (device query failed)"; return g_info.c_str(); }
-    snprintf(buf, sizeof buf, "stmpc 0.1 hip %s %s cu=%d lds=%zu devices=%d", pr.gcnArchName, pr.name,
-             pr.multiProcessorCount, (size_t)pr.sharedMemPerBlock, n);
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { g_info = "stmpc 0.1 hip (device query failed) src=" STMPC_SRC_HASH; return g_info.c_str(); }
+    snprintf(buf, sizeof buf, "stmpc 0.1 hip %s %s cu=%d lds=%zu devices=%d src=%s", pr.gcnArchName, pr.name,
+             pr.multiProcessorCount, (size_t)pr.sharedMemPerBlock, n, STMPC_SRC_HASH);
     g_info = buf;
     return g_info.c_str();
 }
@@ -299,6 +305,8 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (c->sticky.ensure(2 * sizeof(unsigned)) || hipMemset(c->sticky.p, 0, 2 * sizeof(unsigned)) != hipSuccess) { stmpc_destroy(c); return fail(STMPC_ENOMEM, "device allocation failed"); }
     if (const char *w = getenv("STMPC_TUBE")) { int v = atoi(w); if (v >= 0 && v <= 4096) c->tube_w = v; }
     if (const char *w = getenv("STMPC_PRIO")) { int v = atoi(w); if (v >= 0) c->prio_thr = v; }
+    if (const char *w = getenv("STMPC_PRIO_MODE")) c->prio_mode = atoi(w);
+    if (getenv("STMPC_BP16")) c->bp16 = true;
     if (const char *w = getenv("STMPC_RETRY_MOVE")) { int v = atoi(w); if (v >= 0 && v <= 4) c->retry_move = v; }
     if (const char *w = getenv("STMPC_RETRY")) { double x[3]; if (sscanf(w, "%lf,%lf,%lf", &x[0], &x[1], &x[2]) == 3 && x[0] > 1.0 && x[1] > 1.0 && x[2] > 1.0) for (int i = 0; i < 3; ++i) c->retry_mult[i] = x[i]; }
     if (const char *w = getenv("STMPC_RETIRE_CUS")) { int v = atoi(w); if (v >= 0 && v < 256) c->retire_cus = v; }
@@ -399,6 +407,32 @@ void host_t_values(const stmpc_params *p, int H, double *t) {
     if (H > 2) { double d = t[1] - t[0]; for (int i = 2; i < H; ++i) t[i] = 0.0 + (double)i * d; }
 }
 
+// Largest double q >= 0 with RN(sqrt(q)) <= m (-1 if there is none), and smallest double q >= 0 with RN(sqrt(q)) >= m (+inf if none).
+// sqrt is correctly rounded on the host and on the device and monotone, so bisection over the bit patterns of the non-negative doubles is exact.
+double (*volatile host_sqrt)(double) = sqrt;
+double q_largest_sqrt_le(double m) {
+    if (!(m >= 0.0)) return -1.0;
+    uint64_t lo = 0, hi = 0x7FF0000000000000ull;            // invariant: sqrt(lo) <= m; answer in [lo, hi]
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        double q; memcpy(&q, &mid, 8);
+        if (host_sqrt(q) <= m) lo = mid; else hi = mid - 1;
+    }
+    double q; memcpy(&q, &lo, 8);
+    return q;
+}
+double q_smallest_sqrt_ge(double m) {
+    if (!(m > 0.0)) return 0.0;                               // sqrt(0) = 0 >= m
+    uint64_t lo = 0, hi = 0x7FF0000000000000ull;            // invariant: sqrt(hi) >= m (sqrt(inf) = inf)
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        double q; memcpy(&q, &mid, 8);
+        if (host_sqrt(q) >= m) hi = mid; else lo = mid + 1;
+    }
+    double q; memcpy(&q, &hi, 8);
+    return q;
+}
+
 int make_devp(const stmpc_params *p, DevP *d) {
     if (!p) return fail(STMPC_EINVAL, "params is NULL");
     if (!(p->ds > 0) || !(p->dt > 0)) return fail(STMPC_EINVAL, "ds and dt must be positive");
@@ -417,6 +451,10 @@ int make_devp(const stmpc_params *p, DevP *d) {
     d->obst_min_s = p->crash_min_s - p->min_allowed;
     d->max_pred_decel = p->max_pred_decel; d->follow_gap = p->follow_gap; d->react_thr = p->react_thr;
     d->crash_thr = p->crash_thr; d->crash_dist_thr = p->comb_min_dist - p->car_length;
+    // (see DevP) es = +sqrt(q): es > thr <=> q > largest q with sqrt(q) <= thr; es < thr <=> q < smallest q with sqrt(q) >= thr;
+    //            es = -sqrt(q): es > thr <=> sqrt(q) < -thr;                    es < thr <=> sqrt(q) > -thr
+    d->q_gt_pos = q_largest_sqrt_le(p->react_thr); d->q_lt_pos = q_smallest_sqrt_ge(p->react_thr);
+    d->q_gt_neg = q_smallest_sqrt_ge(-p->react_thr); d->q_lt_neg = q_largest_sqrt_le(-p->react_thr);
     d->H = H;
     d->dlen = (int)(p->car_length / p->ds);      // st.py:37
     for (int t = 0; t < H; ++t) {
@@ -481,13 +519,26 @@ bool build_guide_table(const DevP &dp, std::vector<unsigned char> &tab, int &ima
     return true;
 }
 
+// Synchronous entries that reuse the counters: an error flag raised by an earlier asynchronous solve and not yet seen by
+// stmpc_get_stats / stmpc_check_error is moved to the context's sticky word first (k_predict does the same on the device).
+int latch_solver_error(stmpc_ctx *c) {
+    if (!c->counters.p) return STMPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    unsigned cur = 0;
+    HIPCHK(hipMemcpy(&cur, (const unsigned *)c->counters.p + STMPC_CNT_ERR, sizeof cur, hipMemcpyDeviceToHost));
+    if (cur) { const unsigned one = 1u; HIPCHK(hipMemcpy(c->sticky.p, &one, sizeof one, hipMemcpyHostToDevice)); }
+    return STMPC_OK;
+}
+
+int g_pred_dbg = 0;      // (analysis: parts of k_predict switched off for timing, stmpc_debug_predict_ms only)
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
                     CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st,
                     unsigned *sticky = nullptr, const unsigned char *guide_tab = nullptr, int guide_imax = 0, int guide_D = 0, u16 *guide = nullptr) {
-    int blocks = (N + 63) / 64;
+    constexpr int E = PredShape<KMAX>::E;          // episodes per wavefront (k_predict)
+    int blocks = (N + E - 1) / E;
     hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky,
-                       guide_tab, guide_imax, guide_D, guide);
+                       guide_tab, guide_imax, guide_D, guide, g_pred_dbg);
 }
 
 }  // namespace
@@ -569,24 +620,33 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     // an LDS tier whose window covers every cell cannot overflow: the HBM-scratch tier is only needed beyond that
     const bool need_hbm_tier = (nt == 0) || tierW[nt - 1] < Wg || tierPW[nt - 1] < tierW[nt - 1];
     if (need_hbm_tier) {
+        // Clean-up launch: when the last LDS window already covers every cell, the only episodes that can reach this tier are those whose
+        // lattice is not start + n*delta (the LDS kernels are compiled for that form) and rounds whose 64 sources' targets do not fit the
+        // penalty buffer -- none in 4096 x 16 benchmark batches.  The launch then exists for correctness only and is sized accordingly: a
+        // full persistent grid costs 13 us per step to start and leave on an empty queue (and its spill prologue writes 9 MB), 16 workgroups 3.
+        const bool cleanup_only = nt > 0 && tierW[nt - 1] >= Wg && !c->tiers_from_env && !c->force_general;
         tierW[nt] = Wg; tierPW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
         tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
-        tierGrid[nt] = c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
+        tierGrid[nt] = cleanup_only ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     }
     const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
     // episode (N x H x W0 x 2 B) instead of per resident workgroup
     // back-pointers: one byte (distance to the predecessor) when no step of the dynamics exceeds 255 cells, else two (its cell)
-    const bool bp_rel8 = ceil(dp.v_max * dp.dt / dp.ds) + 4.0 <= 255.0 && getenv("STMPC_BP16") == nullptr;
+    const bool bp_rel8 = ceil(dp.v_max * dp.dt / dp.ds) + 4.0 <= 255.0 && !c->bp16;
     const size_t bp_elem = bp_rel8 ? 1 : sizeof(u16);
     const size_t bp0_per_episode = (size_t)N * H * tierW[0] * bp_elem;
     bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
                   bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
     if (resume && c->bp_tier[0].cap < bp0_per_episode) {
-        // a growing request: only while it is at most a quarter of what the device has free right now (a process shared with torch / RCCL)
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        if (bp0_per_episode + (size_t)N * (16 + (size_t)tierW[0] * 12) > (free_b + c->bp_tier[0].cap) / 4) resume = false;
+        // a growing request: only while it is at most a quarter of what the device has free right now (a process shared with torch / RCCL).
+        // A request that was turned down is not priced again (a driver round trip per step) until it changes.
+        if (c->resume_refused_for == bp0_per_episode) resume = false;
+        else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            if (bp0_per_episode + (size_t)N * (16 + (size_t)tierW[0] * 12) > (free_b + c->bp_tier[0].cap) / 4) { resume = false; c->resume_refused_for = bp0_per_episode; }
+        }
     }
     const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
     // reserved compute units (experiment, STMPC_CU_RESERVE): the first window's persistent grid covers the remaining units only
@@ -635,15 +695,19 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if (prune_on && c->tube_w > 0) {
         // guided bounding attempt: the table depends on the dynamics and the cost weights only; rebuilt when they change (a few ms on the host)
         const double key[12] = {dp.ds, dp.dt, dp.v_w, dp.a_w, dp.j_w, dp.v_des, dp.v_max, dp.a_min, dp.a_max, dp.j_min, dp.j_max, (double)H};
-        if (memcmp(key, c->guide_key, sizeof key) != 0) {
-            memcpy(c->guide_key, key, sizeof key);
-            // (stream-ordered upload from a buffer the context keeps: an earlier call on this stream may still be reading the previous table)
-            HIPCHK(hipStreamSynchronize(st));
-            c->guide_ok = build_guide_table(dp, c->guide_host, c->guide_imax, c->guide_D);
-            if (c->guide_ok) {
+        if (!c->guide_key_valid || memcmp(key, c->guide_key, sizeof key) != 0) {
+            // A parameter change.  Kernels of earlier calls (on any stream) may still read the previous table and the staging buffer may
+            // still be in flight, so this path waits for the device once -- the only host synchronisation of this entry, documented in
+            // stmpc.h -- and the cache is marked valid only after the upload has been queued successfully.
+            c->guide_key_valid = false; c->guide_ok = false;
+            HIPCHK(hipDeviceSynchronize());
+            const bool built = build_guide_table(dp, c->guide_host, c->guide_imax, c->guide_D);
+            if (built) {
                 if ((rc = c->guide_tab.ensure(c->guide_host.size()))) return rc;
-                HIPCHK(hipMemcpyAsync(c->guide_tab.p, c->guide_host.data(), c->guide_host.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpy(c->guide_tab.p, c->guide_host.data(), c->guide_host.size(), hipMemcpyHostToDevice));
             }
+            memcpy(c->guide_key, key, sizeof key);
+            c->guide_ok = built; c->guide_key_valid = true;
         }
         if (c->guide_ok) { if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc; g_tab = c->guide_tab.as<unsigned char>(); g_cells = c->guide_cells.as<u16>(); }
     }
@@ -678,7 +742,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
     a.guide = g_cells; a.tube_w = c->tube_w; a.tube_dense = c->tube_dense; a.band_dense = c->band_dense;
     a.retry_move = resume ? c->retry_move : 0;
-    a.prio_thr = c->prio_thr; a.prio_mode = getenv("STMPC_PRIO_MODE") ? atoi(getenv("STMPC_PRIO_MODE")) : 0;
+    a.prio_thr = c->prio_thr; a.prio_mode = c->prio_mode;
     a.bp_rel8 = bp_rel8 ? 1 : 0;
     a.force_general = c->force_general ? 1 : 0;
     a.gsh_max = c->gsh_max;
@@ -849,9 +913,47 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         c->stats.solve_ms = ms_all;
         c->stats.dp_kernel_ms = ms_dp;
         c->stats_pending = false;
-        if (cnt[STMPC_CNT_ERR]) { *out = c->stats; return fail(STMPC_EINTERNAL, "solver error flag set on device"); }
+        if (cnt[STMPC_CNT_ERR]) {
+            // reported here, once: cleared so that the next k_predict does not latch it again and blame a later batch
+            HIPCHK(hipMemset((unsigned *)c->counters.p + STMPC_CNT_ERR, 0, sizeof(unsigned)));
+            *out = c->stats;
+            return fail(STMPC_EINTERNAL, "solver error flag set on device");
+        }
     }
     *out = c->stats;
+    return STMPC_OK;
+}
+
+// Analysis entry: time k_predict alone (reps launches between two events) on device-resident states; mask switches parts of the kernel off
+// (1: no table rows, 2: ego treated as standing still, 4: no vehicle loop, 8: no guide loads).  With mask != 0 the table is NOT valid.
+int stmpc_debug_predict_ms(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego, const int32_t *d_k, const double *d_ox,
+                           const double *d_ov, int reps, int mask, float *ms_out) {
+    if (!c || !ms_out || N <= 0 || Kmax <= 0 || Kmax > 8 || reps < 1) return fail(STMPC_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevP dp;
+    int rc = make_devp(p, &dp);
+    if (rc) return rc;
+    const int H = dp.H;
+    if ((rc = c->tab_edge.ensure((size_t)N * H * Kmax * 2 * sizeof(double)))) return rc;
+    if ((rc = c->tab_win.ensure((size_t)N * H * Kmax * 2 * sizeof(int)))) return rc;
+    if ((rc = c->tab_nact.ensure((size_t)N * H * sizeof(int)))) return rc;
+    if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
+    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
+    if ((rc = c->ubound.ensure((size_t)N * sizeof(u64)))) return rc;
+    if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc;
+    CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
+    const bool have_guide = c->guide_ok && c->guide_tab.p;
+    g_pred_dbg = mask;
+    for (int r = 0; r < reps + 2; ++r) {
+        if (r == 2) HIPCHK(hipEventRecord(c->ev0, nullptr));
+        launch_predict<8>(dp, N, Kmax, d_ego, d_k, d_ox, d_ov, tab, c->counters.as<unsigned>(), c->ubound.as<u64>(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                          c->sticky.as<unsigned>(), have_guide ? c->guide_tab.as<unsigned char>() : nullptr, c->guide_imax, c->guide_D, c->guide_cells.as<u16>());
+    }
+    g_pred_dbg = 0;
+    HIPCHK(hipEventRecord(c->ev1, nullptr));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
+    *ms_out /= (float)reps;
     return STMPC_OK;
 }
 
@@ -954,6 +1056,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     HIPCHK(hipMemcpy(c->s_misc0.p, obstacles, cells, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc1.p, distances, cells * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->s_misc2.p, s_values, (size_t)S * 8, hipMemcpyHostToDevice));
+    if ((rc = latch_solver_error(c))) return rc;          // an earlier asynchronous call's flag survives the reset below
     HIPCHK(hipMemset(c->counters.p, 0, 64 * sizeof(unsigned)));
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -969,7 +1072,10 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     HIPCHK(hipMemcpy(s_sequence_out, c->s_misc3.p, (size_t)H * 8, hipMemcpyDeviceToHost));
     unsigned cnt[64];
     HIPCHK(hipMemcpy(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
-    if (cnt[STMPC_CNT_ERR]) return fail(STMPC_EINTERNAL, "grid solver reported a window overflow");
+    if (cnt[STMPC_CNT_ERR]) {
+        HIPCHK(hipMemset((unsigned *)c->counters.p + STMPC_CNT_ERR, 0, sizeof(unsigned)));
+        return fail(STMPC_EINTERNAL, "grid solver reported a window overflow");
+    }
     return STMPC_OK;
 }
 
@@ -1009,9 +1115,9 @@ int stmpc_build_grid(stmpc_ctx *c, const stmpc_params *p, const double *state5, 
     }
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     unsigned *counters = c->counters.as<unsigned>();
-    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (Kalloc <= 8) launch_predict<8>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->sticky.as<unsigned>());
+    else if (Kalloc <= 16) launch_predict<16>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->sticky.as<unsigned>());
+    else launch_predict<32>(dp, 1, Kalloc, c->s_ego.as<double>(), c->s_k.as<int>(), c->s_ox.as<double>(), c->s_ov.as<double>(), tab, counters, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->sticky.as<unsigned>());
     dim3 grid((S + 255) / 256, H);
     hipLaunchKernelGGL(k_build_grid, grid, dim3(256), 0, nullptr, dp, tab, Kalloc, start_s, S, c->s_misc0.as<uint8_t>(),
                        c->s_misc1.as<double>(), c->s_misc2.as<double>());
@@ -1210,10 +1316,12 @@ int stmpc_finer_fit_batch(stmpc_ctx *c, const stmpc_params *p, double dt, double
     return STMPC_OK;
 }
 
-int stmpc_st_control_batch_device(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *d_ego,
-                                  const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
-                                  int32_t *d_bt, double *d_cost, double *d_speed, double *d_fine, int32_t *d_fine_len,
-                                  void *stream) {
+// st.do_st_control on device buffers.  `refused`: the word a path that cannot be re-sampled raises (the public entry: the context's sticky flag,
+// so that stmpc_check_error reports STMPC_EINVAL; the combined controller: null -- there k_cc_decide raises it only when that speed is used).
+static int st_control_device(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *d_ego,
+                             const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
+                             int32_t *d_bt, double *d_cost, double *d_speed, double *d_fine, int32_t *d_fine_len,
+                             void *stream, unsigned *refused) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
     if (N == 0) return STMPC_OK;
     if (!d_speed) return fail(STMPC_EINVAL, "NULL device pointer (speed)");
@@ -1229,9 +1337,19 @@ int stmpc_st_control_batch_device(stmpc_ctx *c, const stmpc_params *p, double ti
     a.N = N; a.Hs = H; a.n_max = STMPC_QP_NMAX; a.use_qp = (tick < p->dt) ? 1 : 0;
     a.path_idx = d_path; a.best_t = d_bt; a.ego = d_ego; a.ds = p->ds;
     a.out = d_fine; a.out_len = d_fine_len; a.speed = d_speed;
+    a.refused = refused;
     launch_finer_fit(a, false, a.use_qp ? ff_group_width(H, tick, p->dt) : 64, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return STMPC_OK;
+}
+
+int stmpc_st_control_batch_device(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *d_ego,
+                                  const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
+                                  int32_t *d_bt, double *d_cost, double *d_speed, double *d_fine, int32_t *d_fine_len,
+                                  void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    // a path that cannot be re-sampled (its speed is NaN): stmpc_check_error returns STMPC_EINVAL
+    return st_control_device(c, p, tick, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_speed, d_fine, d_fine_len, stream, c->sticky.as<unsigned>() + 1);
 }
 
 int stmpc_st_control_batch(stmpc_ctx *c, const stmpc_params *p, double tick, int N, int Kmax, const double *ego,
@@ -1277,7 +1395,15 @@ int stmpc_st_control_batch(stmpc_ctx *c, const stmpc_params *p, double tick, int
     if (fine) HIPCHK(hipMemcpy(fine, c->f_out.p, (size_t)N * STMPC_QP_NMAX * 8, hipMemcpyDeviceToHost));
     if (fine_len) HIPCHK(hipMemcpy(fine_len, c->f_olen.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     stmpc_stats s;
-    return stmpc_get_stats(c, &s);
+    if ((rc = stmpc_get_stats(c, &s))) return rc;
+    // (this entry is synchronous: a refused re-sampling is its own error, not left for a later stmpc_check_error)
+    unsigned refused = 0;
+    HIPCHK(hipMemcpy(&refused, c->sticky.as<unsigned>() + 1, sizeof refused, hipMemcpyDeviceToHost));
+    if (refused) {
+        HIPCHK(hipMemset(c->sticky.as<unsigned>() + 1, 0, sizeof refused));
+        return fail(STMPC_EINVAL, "finer_fit: a fine grid longer than STMPC_QP_NMAX samples is not supported (speed = NaN, fine_len = -1 for those states)");
+    }
+    return STMPC_OK;
 }
 
 }  // extern "C"
@@ -1383,8 +1509,8 @@ int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmp
     }
     // 2. the controller on the start state (st.do_st_control; also the path of the strictly-better comparison, dqn.py:157-164)
     HIPCHK(hipMemsetAsync(c->cc_fine.p, 0, (size_t)N * STMPC_QP_NMAX * 8, st_));
-    if ((rc = stmpc_st_control_batch_device(c, p, g->tick_length, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(),
-                                            c->cc_cost.as<double>(), c->cc_speed.as<double>(), c->cc_fine.as<double>(), c->cc_fine_len.as<int32_t>(), stream))) return rc;
+    if ((rc = st_control_device(c, p, g->tick_length, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(),
+                                c->cc_cost.as<double>(), c->cc_speed.as<double>(), c->cc_fine.as<double>(), c->cc_fine_len.as<int32_t>(), stream, nullptr))) return rc;
     // 3. the decision
     hipLaunchKernelGGL(k_cc_decide, dim3(blocks), dim3(64), 0, st_, cc, N, d_ego5_start, d_first_action, d_last_choice_rl, st, (const int *)c->cc_pcrash.as<int>(),
                        (const double *)c->cc_speed.as<double>(), (const double *)c->cc_fine.as<double>(), (const int *)c->cc_fine_len.as<int>(), STMPC_QP_NMAX,

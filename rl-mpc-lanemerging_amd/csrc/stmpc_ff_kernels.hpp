@@ -41,6 +41,8 @@ struct FFArgs {
     int *out_len;             // [N]; -1: more fine samples than the launch's group width (at most 64 are supported)
     int *iters;               // [N]; iterations, negated when the cap was hit without convergence
     double *speed;            // [N]  (x_1 - x_0) / dt, or the current speed when the path has one point (st.py:774-783)
+    unsigned *refused;        // or null: word that is OR-ed with 1 when a path cannot be re-sampled (more fine samples than the group holds);
+                              // the controller entries point it at the context's sticky flag that stmpc_check_error reports as STMPC_EINVAL
 };
 
 // A problem with at most GW (16, 32 or 64) fine samples occupies an aligned group of GW lanes, so a wavefront carries
@@ -232,7 +234,10 @@ __global__ void __launch_bounds__(64) k_finer_fit(FFArgs a) {
     int n = (int)rint(t_last / k.dt + 1.0);
     if ((double)(n - 1) * k.dt > t_last) n -= 1;
     if (n < 2 || n > GW) {
-        if (lane == 0) { if (a.out_len) a.out_len[e] = -1; if (a.iters) a.iters[e] = 0; if (a.speed) a.speed[e] = __builtin_nan(""); }
+        if (lane == 0) {
+            if (a.out_len) a.out_len[e] = -1; if (a.iters) a.iters[e] = 0; if (a.speed) a.speed[e] = __builtin_nan("");
+            if (a.refused) atomicOr(a.refused, 1u);
+        }
         return;
     }
     const double bi_all = ff_interp_lane(sc, gbase, len, k.cdt, (double)lane * k.dt);   // all lanes: the shuffles inside need them

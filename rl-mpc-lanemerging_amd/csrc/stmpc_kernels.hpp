@@ -76,6 +76,11 @@ struct DevP {
     double d_w, v_w, a_w, j_w, v_des, v_max, a_min, a_max, j_min, j_max, min_allowed;
     double car_length, obst_min_s /* crash_min_s - min_allowed, st.py:46 */;
     double max_pred_decel, follow_gap, react_thr, crash_thr, crash_dist_thr /* comb_min_dist - car_length, st.py:800 */;
+    // prediction.py:24,64-66 compare get_ego_s = +-sqrt(q) of the predicted ego with react_thr.  sqrt is correctly rounded and monotone, so each
+    // comparison is a comparison of q itself with a double the host finds by bisection (make_devp): no square root in k_predict's recurrence.
+    //   ramp side of the merge point (es = +sqrt q):  es > thr <=> q > q_gt_pos    es < thr <=> q < q_lt_pos
+    //   before the ramp's end point  (es = -sqrt q):  es > thr <=> q < q_gt_neg    es < thr <=> q > q_lt_neg
+    double q_gt_pos, q_lt_pos, q_gt_neg, q_lt_neg;
     double unc[STMPC_MAXH];     // start_unc + unc_per_s * t_values[t]   (st.py:40)
     int    dunc[STMPC_MAXH];    // int(unc / ds)                         (st.py:41)
     int    H;
@@ -230,6 +235,18 @@ struct CarTab {
     int    *num_s;    // [N]   S of the episode
 };
 
+// Episodes per wavefront of k_predict: the predictor recurrence of an episode is one lane's serial chain, everything else about
+// an episode is spread over the wavefront's 64 lanes.
+template <int KMAX> struct PredShape { static constexpr int E = KMAX <= 8 ? 4 : (KMAX <= 16 ? 2 : 1); };
+
+// k_predict: one WAVEFRONT per E episodes, two phases.
+//   1  lanes 0..E-1: the predictor recurrence of their episode (prediction.py:22-105 applied H-1 times, st.py:42-43) -- the only part that is
+//      serial (layer after layer, vehicle after vehicle); the vehicles' positions of every layer go to LDS, and so do the cells of the guide.
+//   2  all lanes: one (layer, vehicle) pair each, KMAX lanes per layer: the obstructing-vehicle list of st.py:44-65 -- front / back edge, blocked
+//      index window, the break / continue rules as a ballot over the layer's lanes, entries compacted in vehicle order -- written with one
+//      row of the table per lane group (coalesced), and the guide's cell of the layer checked against each listed vehicle.
+// (Round 3 ran all of it as one thread per episode: 64 wavefronts for 4096 episodes, each store instruction touching 64 table rows 5 KB
+// apart; 119 us of serial prefix per step.)
 template <int KMAX>
 __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const double *__restrict__ ego,
                                                 const int *__restrict__ k_count,
@@ -242,109 +259,275 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                                                 unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */,
                                                 unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */,
                                                 const unsigned char *__restrict__ guide_tab /* [(imax+1)*(2D+1)][H-1] steps of the unobstructed optimum, or null */,
-                                                int guide_imax, int guide_D, u16 *guide /* [N][H] out */) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
+                                                int guide_imax, int guide_D, u16 *guide /* [N][H] out */, int dbg = 0) {
+    constexpr int E = PredShape<KMAX>::E;
+    constexpr int LPI = 64 / KMAX;                       // layers per iteration of phase 2
+    __shared__ double xs_l[E][STMPC_MAXH][KMAX];         // vehicle positions per layer (phase 1 -> phase 2)
+    __shared__ double unc_l[STMPC_MAXH];
+    __shared__ int dunc_l[STMPC_MAXH];
+    __shared__ double ep_start[E], ep_slast[E];
+    __shared__ int ep_S[E], ep_k[E], gbad_l[E];
+    __shared__ int gcell_l[E][STMPC_MAXH];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;                // (the grid has at least N threads)
     // the previous solve's error flag is latched before the counters are reused (same wavefront: the read precedes lane 63's store)
-    if (e == 0 && sticky && counters[63 /* STMPC_CNT_ERR */]) atomicOr(&sticky[0], 1u);
-    if (e < 64) counters[e] = 0u;
-    if (e >= N) return;
-    if (ubound) ubound[e] = 0ull;
-    if (queue1) queue1[e] = -1;
-    if (proxy0) proxy0[e] = 0u;
-    if (resume_t) resume_t[e] = 0;
-    if (prio_key) {
-        // the slower the ego starts, the more of the lattice stays below the cost bound (rank correlation of the exact pass's
-        // time with the start speed: -0.57 on the benchmark states): slow starters are handed out first, so that the long
-        // searches -- and the window overflows they cause -- happen early in the launch instead of in its tail
-        double f = ego[e * 5 + 2] / (p.v_max > 0.0 ? p.v_max : 1.0);
-        f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
-        prio_key[e] = (unsigned char)(f * 255.0);
+    if (g == 0 && sticky && counters[63 /* STMPC_CNT_ERR */]) atomicOr(&sticky[0], 1u);
+    if (g < 64) counters[g] = 0u;
+    if (g < N) {
+        if (ubound) ubound[g] = 0ull;
+        if (queue1) queue1[g] = -1;
+        if (proxy0) proxy0[g] = 0u;
+        if (resume_t) resume_t[g] = 0;
     }
-    DState<KMAX> s;
-    s.ex = ego[e * 5 + 0]; s.ey = ego[e * 5 + 1]; s.ev = ego[e * 5 + 2]; s.ea = ego[e * 5 + 3];
-    double start_s = ego[e * 5 + 4];
-    int k = k_count[e];
-    k = k < 0 ? 0 : (k > KMAX ? KMAX : k);
-    k = k > Kmax ? Kmax : k;                 // the table rows hold Kmax entries (device-pointer callers are not validated on the host)
-    s.k = k;
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-        bool in = (i < k) && (i < Kmax);
-        s.xs[i] = in ? other_x[(size_t)e * Kmax + i] : 0.0;
-        s.vs[i] = in ? other_v[(size_t)e * Kmax + i] : 0.0;
-    }
-    int S = dev_num_s(p, start_s);
-    tab.num_s[e] = S;
-    // s_values[S-1] per numpy's arange fill
-    double s1 = start_s + p.ds;
-    double delta = s1 - start_s;
-    double s_last = (S - 1 == 1) ? s1 : start_s + (double)(S - 1) * delta;
-    // Guide of the guided bounding attempt (SolveArgs::guide): the unobstructed optimum from the lattice state nearest to the episode's start
-    // (cells covered per layer at the start speed, and one layer earlier), usable if it stays on the lattice and clear of every vehicle and of
-    // its penalty zone.  Approximate on purpose: it only centres a search whose result is checked like any other bound.
-    const unsigned char *grow = nullptr;
+    if (lane < p.H) { unc_l[lane] = p.unc[lane]; dunc_l[lane] = p.dunc[lane]; }
+    const int e0 = blockIdx.x * E;
     bool g_ok = false;
-    int g_cell = 0;
-    if (guide_tab) {
-        const double cps = p.dt / delta;
-        int i1 = (int)rint(s.ev * cps), i2 = (int)rint((s.ev - s.ea * p.dt) * cps);
-        i1 = i1 < 0 ? 0 : (i1 > guide_imax ? guide_imax : i1);
-        int d = i1 - i2; d = d < -guide_D ? -guide_D : (d > guide_D ? guide_D : d);
-        if (i1 - d < 0) d = i1;
-        if (i1 - d > guide_imax) d = i1 - guide_imax;
-        grow = guide_tab + ((size_t)i1 * (2 * guide_D + 1) + (size_t)(d + guide_D)) * (size_t)(p.H - 1);
-        g_ok = true;
-        guide[(size_t)e * p.H] = 0;
+    if (lane < E) { gbad_l[lane] = 0; ep_k[lane] = 0; ep_S[lane] = 0; }
+    // ---- phase 1: the recurrence (lanes 0..E-1).
+    // prediction.py:22-105 restated for this use: H-1 applications of predict_step_without_ego on its own output, of which only the vehicles'
+    // positions are kept.  What that allows (same bits in every position): the ego's speed and acceleration are never read back; the crash flag
+    // and the per-vehicle accelerations are not needed; get_ego_s of the predicted ego feeds two comparisons only, which are comparisons of the
+    // squared distance with precomputed doubles (DevP::q_*); an ego that is told to stand still does not move, so the unit vector of
+    // prediction.py:49-54 is formed only for a moving ego on the ramp; and the search for the vehicle the phantom ego tails in the NEXT
+    // layer (prediction.py:28-40: compares the vehicles' new positions with the ego's new position) rides along the follower loop.
+    // The code is branch-free apart from wave-uniform tests: the lanes' serial chain is what the whole launch waits for.
+    // (every lane runs the recurrence of episode e0 + (lane mod E): 64 / E identical copies, of which the first writes.  Measured on gfx950
+    // (scripts/lab/exp/issue_latency.hip): a wavefront with 4 of its 64 lanes enabled issues independent fp64 operations 3.7 times more slowly
+    // than the same wavefront with all lanes enabled)
+    const int pl = lane & (E - 1);
+    const bool wr = lane < E;
+    int k = 0;
+    if (e0 + pl < N) {
+        k = k_count[e0 + pl];
+        k = k < 0 ? 0 : (k > KMAX ? KMAX : k);
+        k = k > Kmax ? Kmax : k;                 // the table rows hold Kmax entries (device-pointer callers are not validated on the host)
     }
-    int g_next = grow ? (int)grow[0] : 0;          // the row's steps are fetched one layer ahead: the load's latency hides behind the layer's work
-    for (int t = 0; t < p.H; ++t) {
-        if (t != 0) dev_predict_without_ego<KMAX>(p, s, p.dt, 5.0);            // st.py:42-43
-        double g_sn = 0.0;
-        if (grow && t != 0) {
-            const int stp = g_next;
-            if (t < p.H - 1) g_next = (int)grow[t];
-            g_ok = g_ok && stp != 255;
-            g_cell += stp;
-            g_ok = g_ok && g_cell < S;
-            guide[(size_t)e * p.H + t] = (u16)(g_cell < 65535 ? g_cell : 65535);
-            g_sn = start_s + (double)g_cell * delta;
-        }
-        double unc = p.unc[t];
-        int dunc = p.dunc[t];
-        size_t rowbase = ((size_t)e * p.H + t) * Kmax;
-        int na = 0;
-        bool stop = false;
+    const int kw = wave_max_i(k);                // most vehicles of any of the wavefront's episodes (a DPP reduction: all lanes take part)
+    if (e0 + pl < N) {
+        const int e = e0 + pl;
+        double ex = ego[e * 5 + 0], ey = ego[e * 5 + 1];
+        const double ev0 = ego[e * 5 + 2], ea0 = ego[e * 5 + 3];
+        const double start_s = ego[e * 5 + 4];
+        double xs[KMAX], vs[KMAX];
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) {
-            if (c < k && !stop) {
-                double o = s.xs[c] - (-51.0);                                  // control.py:388-389
-                if (o < p.obst_min_s) stop = true;                             // st.py:46-47 break
-                else if (o > s_last + p.car_length) { /* continue */ }         // st.py:48-49
-                else {
-                    double front = o - p.car_length - unc;
-                    double back = o + p.car_length + unc;
-                    int i0 = (int)((o - start_s) / p.ds);                      // st.py:60 (trunc toward 0)
-                    int imin = i0 - p.dlen - dunc; imin = imin < 0 ? 0 : imin;
-                    int imax = i0 + p.dlen + dunc; imax = imax > S ? S : imax;
-                    if (!(imin < S && imax > 0)) { imin = 0; imax = 0; }       // st.py:63
-                    tab.edge[(rowbase + na) * 2 + 0] = front;
-                    tab.edge[(rowbase + na) * 2 + 1] = back;
-                    tab.win[(rowbase + na) * 2 + 0] = imin;
-                    tab.win[(rowbase + na) * 2 + 1] = imax;
-                    ++na;
-                    if (grow && t != 0) {                                          // the guide's cell of this layer against this vehicle
-                        const double gd = __builtin_fmin(fabs(g_sn - front), fabs(g_sn - back));
-                        if ((g_cell >= imin && g_cell < imax) || gd < p.min_allowed) g_ok = false;
-                    }
+        for (int i = 0; i < KMAX; ++i) {
+            bool in = (i < k) && (i < Kmax);
+            xs[i] = in ? other_x[(size_t)e * Kmax + i] : 0.0;
+            vs[i] = in ? other_v[(size_t)e * Kmax + i] : 0.0;
+        }
+        const int S = dev_num_s(p, start_s);
+        if (wr) tab.num_s[e] = S;
+        // s_values[S-1] per numpy's arange fill
+        const double s1 = start_s + p.ds;
+        const double delta = s1 - start_s;
+        if (wr) {
+            ep_start[pl] = start_s;
+            ep_slast[pl] = (S - 1 == 1) ? s1 : start_s + (double)(S - 1) * delta;
+            ep_S[pl] = S; ep_k[pl] = k;
+        }
+        // Guide of the guided bounding attempt (SolveArgs::guide): the unobstructed optimum from the lattice state nearest to the episode's start
+        // (cells covered per layer at the start speed, and one layer earlier), usable if it stays on the lattice and clear of every vehicle and of
+        // its penalty zone (checked in phase 2).  Approximate on purpose: it only centres a search whose result is checked like any other bound.
+        const unsigned char *grow = nullptr;
+        int g_cell = 0;
+        if (guide_tab) {
+            const double cps = p.dt / delta;
+            int i1 = (int)rint(ev0 * cps), i2 = (int)rint((ev0 - ea0 * p.dt) * cps);
+            i1 = i1 < 0 ? 0 : (i1 > guide_imax ? guide_imax : i1);
+            int d = i1 - i2; d = d < -guide_D ? -guide_D : (d > guide_D ? guide_D : d);
+            if (i1 - d < 0) d = i1;
+            if (i1 - d > guide_imax) d = i1 - guide_imax;
+            grow = guide_tab + ((size_t)i1 * (2 * guide_D + 1) + (size_t)(d + guide_D)) * (size_t)(p.H - 1);
+            g_ok = true;
+        }
+        if (prio_key && wr) {
+            // the slower the ego starts, the more of the lattice stays below the cost bound (rank correlation of the exact pass's
+            // time with the start speed: -0.57 on the benchmark states)
+            double f = ev0 / (p.v_max > 0.0 ? p.v_max : 1.0);
+            f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+            prio_key[e] = (unsigned char)(f * 255.0);
+        }
+        // The loop's launch constants, made opaque so that they stay in registers: left to itself the compiler re-loads them from the kernel
+        // argument segment inside the loop (DevP is large), and a scalar load + wait in a lone wavefront's serial chain costs hundreds of cycles.
+        double c_carlen = p.car_length, c_thr = p.react_thr, c_qgn = p.q_gt_neg, c_qgp = p.q_gt_pos, c_qln = p.q_lt_neg, c_qlp = p.q_lt_pos;
+        double c_dt = p.dt, c_gap = p.follow_gap, c_dcl = p.max_pred_decel;
+        int c_H = p.H;
+        asm volatile("" : "+s"(c_carlen), "+s"(c_thr), "+s"(c_qgn), "+s"(c_qgp), "+s"(c_qln), "+s"(c_qlp), "+s"(c_dt), "+s"(c_gap), "+s"(c_dcl), "+s"(c_H));
+        if (dbg & 16) c_H = 1;
+        const bool dcl_nonpos = c_dcl <= 0.0;
+        // control.py:373-380 of a position as the two comparisons with react_thr that prediction.py makes (x*x for the squares, as dev_ego_s);
+        // straight-line mask logic, no short-circuit branches
+        const double mpx = -50.9, mpy = 1.72, mp2x = 1.5, mp2y = -1.5, mp3x = -51.0;
+        const double common_s = mp2x - mp3x;
+        auto zone = [&](double x, double y, bool &gt, bool &lt) {
+            const double dx = x - mpx, dy = y - mpy;
+            const double q = dx * dx + dy * dy;
+            const double lin = x - mp2x + common_s;
+            const bool neg = x < mpx, pos = x < mp2x;                       // (neg implies pos)
+            const bool mid = pos & !neg, hwy = !pos;
+            gt = (neg & (q < c_qgn)) | (mid & (q > c_qgp)) | (hwy & (lin > c_thr));
+            lt = (neg & (q > c_qln)) | (mid & (q < c_qlp)) | (hwy & (lin < c_thr));
+        };
+        // what predict_step_without_ego will decide from a state (prediction.py:24-44): stand still / park / tail the vehicle ahead of the first one behind
+        bool lt, gt_unused;
+        zone(ex, ey, gt_unused, lt);
+        bool found = false;                      // some vehicle is behind the ego
+        double lx = 0.0, lv = 0.0;               // position and speed of the last vehicle that is not (before the first one that is)
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            const bool in = i < k;
+            const bool b = xs[i] < ex;
+            const bool take = in && !found && !b;
+            lx = take ? xs[i] : lx; lv = take ? vs[i] : lv;
+            found = found || (in && b);
+        }
+        bool park = k > 0 && xs[0] < ex;         // prediction.py:28
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) if (wr) xs_l[pl][0][c] = xs[c];
+        if (wr) gcell_l[pl][0] = 0;
+        int g_next = grow ? (int)grow[0] : 0;          // the row's steps are fetched one layer ahead: the load's latency hides behind the layer's work
+        for (int t = 1; t < c_H; ++t) {
+            // -- predict_step_without_ego's choice (prediction.py:24-44)
+            const bool still = lt || k == 0;
+            const bool tail = !still && !park;
+            double sel = 0.0;
+            if (dbg & 2) { lt = true; }
+            if (!still && park) { ex = -20.0; ey = -10.0; }
+            if (tail) { if (found) ex = lx - c_carlen - 5; sel = lv; }
+            // -- the ego's step (prediction.py:47-59).  An ego that stands still keeps its position bit for bit: cx + (d0 / nrm) * (0 * dt) = cx.
+            double px = ex, py = ey;
+            const bool ramp = ex < mp2x;
+            const bool curved = ramp && sel != 0.0;
+            if (__ballot(curved) != 0ull) {
+                if (curved) {
+                    double d0 = mp2x - ex, d1 = mp2y - ey;
+                    // np.linalg.norm of the 2-vector as this image's BLAS evaluates it: fma(d1,d1,d0*d0)
+                    const double nrm = sqrt(__builtin_fma(d1, d1, d0 * d0));
+                    d0 /= nrm; d1 /= nrm;
+                    const double step = sel * c_dt;
+                    d0 *= step; d1 *= step;
+                    px = ex + d0; py = ey + d1;
                 }
             }
+            if (!ramp) px = ex + sel * c_dt;
+            if (ramp && py < -1.6) py = -1.6;
+            bool merged;
+            zone(px, py, merged, lt);                  // prediction.py:64-66 (and the next layer's prediction.py:24)
+            // -- the vehicles, front to back (prediction.py:72-97), and the next layer's search for the vehicle to tail.
+            // The loop-carried chain (leader's new speed and position -> this vehicle's) is kept to VALU operations without mask round trips:
+            // which vehicle takes the ego as its leader depends on the OLD positions only and is settled before the loop, and
+            //   nv = ov + acc * dt,  acc = (sd < 0 && xd < gap) ? max(sd, decel) : 0        (prediction.py:83-91; ov + 0 * dt = ov)
+            // with max(sd, decel) for sd < 0, else 0, as min(max(sd, decel), 0).
+            bool lead_ego[KMAX];
+            {
+                bool enc = false;
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i) {
+                    const bool first_behind = xs[i] < px && !enc;                   // prediction.py:78-82
+                    enc = enc || first_behind;
+                    lead_ego[i] = first_behind && merged;
+                }
+            }
+            double last_x = __builtin_inf(), last_speed = 0.0;
+            found = false; lx = 0.0; lv = 0.0;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) {
+                if (i < kw && !(dbg & 4)) {                                                      // (wave-uniform)
+                    const double ov = vs[i], ox = xs[i];
+                    last_x = lead_ego[i] ? px : last_x; last_speed = lead_ego[i] ? sel : last_speed;
+                    const double sd = last_speed - ov;
+                    const double xd = last_x - ox;
+                    double acc = __builtin_fmin(__builtin_fmax(sd, c_dcl), 0.0);
+                    if (!dcl_nonpos) acc = (sd < 0) ? dmax_py(sd, c_dcl) : 0.0;      // (launch-uniform: a positive "deceleration" takes the literal form)
+                    acc = (xd < c_gap) ? acc : 0.0;
+                    const double nv = ov + acc * c_dt;
+                    const double nx = ox + nv * c_dt;
+                    last_x = nx; last_speed = nv;
+                    xs[i] = nx; vs[i] = nv;
+                    const bool in = i < k;
+                    const bool b = nx < px;
+                    const bool take = in && !found && !b;
+                    lx = take ? nx : lx; lv = take ? nv : lv;
+                    found = found || (in && b);
+                }
+            }
+            park = k > 0 && xs[0] < px;
+            ex = px; ey = py;
+            if (wr) {
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) xs_l[pl][t][c] = xs[c];
+            }
+            if (grow) {
+                const int stp = g_next;
+                if (t < c_H - 1 && !(dbg & 8)) g_next = (int)grow[t];
+                g_ok = g_ok && stp != 255;
+                g_cell += stp;
+                g_ok = g_ok && g_cell < S;
+            }
+            if (wr) gcell_l[pl][t] = g_cell;
         }
-        tab.nact[(size_t)e * p.H + t] = na;
     }
-    if (grow && !g_ok) guide[(size_t)e * p.H] = 0xffff;
-    // Episodes whose unobstructed optimum is clear of the traffic behave: their bounds are tight, their exact passes do not overflow the window (offline:
-    // none of 245).  The others hold every long chain of a step (poor bound -> wide search -> window overflow -> second window), so they go first.
-    if (prio_key && grow) prio_key[e] = (unsigned char)((g_ok ? 128 : 0) + (prio_key[e] >> 1));
+    __syncthreads();
+    // ---- phase 2: the obstructing-vehicle list of every layer, KMAX lanes per layer
+    const int c = lane & (KMAX - 1);
+    const int grp = lane & ~(KMAX - 1);
+    const u64 gmask = KMAX >= 64 ? ~0ull : ((1ull << KMAX) - 1ull);
+    for (int el = 0; el < E; ++el) {
+        const int e = e0 + el;
+        if (e >= N || (dbg & 1)) break;                                                         // (wave-uniform)
+        const int k = ep_k[el], S = ep_S[el];
+        const double start_s = ep_start[el], s_last = ep_slast[el];
+        const double delta = (start_s + p.ds) - start_s;
+        bool bad = false;
+        for (int tb = 0; tb < p.H; tb += LPI) {
+            const int t = tb + (lane / KMAX);
+            const bool tin = t < p.H;
+            const int tt = tin ? t : 0;
+            const double o = xs_l[el][tt][c] - (-51.0);                            // control.py:388-389
+            const bool inb = tin && c < k;
+            const bool below = inb && o < p.obst_min_s;                            // st.py:46-47 break: this vehicle and every later one
+            const u64 bm = (__ballot(below) >> grp) & gmask;
+            const bool stop = (bm & ((2ull << c) - 1ull)) != 0ull;
+            const bool valid = inb && !stop && !(o > s_last + p.car_length);       // st.py:48-49 continue
+            const u64 vm = (__ballot(valid) >> grp) & gmask;
+            const int slot = __popcll(vm & ((1ull << c) - 1ull));
+            const size_t rowbase = ((size_t)e * p.H + tt) * Kmax;
+            if (valid) {
+                const double unc = unc_l[tt];
+                const int dunc = dunc_l[tt];
+                const double front = o - p.car_length - unc;
+                const double back = o + p.car_length + unc;
+                const int i0 = (int)((o - start_s) / p.ds);                        // st.py:60 (trunc toward 0)
+                int imin = i0 - p.dlen - dunc; imin = imin < 0 ? 0 : imin;
+                int imax = i0 + p.dlen + dunc; imax = imax > S ? S : imax;
+                if (!(imin < S && imax > 0)) { imin = 0; imax = 0; }               // st.py:63
+                double2 ed; ed.x = front; ed.y = back;
+                int2 wd; wd.x = imin; wd.y = imax;
+                *(double2 *)&tab.edge[(rowbase + slot) * 2] = ed;
+                *(int2 *)&tab.win[(rowbase + slot) * 2] = wd;
+                if (guide_tab && tt != 0) {                                        // the guide's cell of this layer against this vehicle
+                    const int g_cell = gcell_l[el][tt];
+                    const double g_sn = start_s + (double)g_cell * delta;
+                    const double gd = __builtin_fmin(fabs(g_sn - front), fabs(g_sn - back));
+                    if ((g_cell >= imin && g_cell < imax) || gd < p.min_allowed) bad = true;
+                }
+            }
+            if (tin && c == 0) {
+                tab.nact[(size_t)e * p.H + tt] = __popcll(vm);
+                if (guide_tab && tt != 0) { const int gc = gcell_l[el][tt]; guide[(size_t)e * p.H + tt] = (u16)(gc < 65535 ? gc : 65535); }
+            }
+        }
+        if (__ballot(bad) != 0ull && lane == 0) gbad_l[el] = 1;
+    }
+    __syncthreads();
+    if (lane < E && e0 + lane < N && guide_tab) {
+        const int e = e0 + lane;
+        g_ok = g_ok && gbad_l[lane] == 0;
+        guide[(size_t)e * p.H] = g_ok ? (u16)0 : (u16)0xffff;
+        // Episodes whose unobstructed optimum is clear of the traffic behave: their bounds are tight, their exact passes do not overflow the window (offline:
+        // none of 245).  The others hold every long chain of a step (poor bound -> wide search -> window overflow -> second window), so they go first.
+        if (prio_key) prio_key[e] = (unsigned char)((g_ok ? 128 : 0) + (prio_key[e] >> 1));
+    }
 }
 
 // One-step prediction exposed through the C-ABI (stmpc_predict_batch).

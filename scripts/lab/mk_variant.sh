@@ -2,4 +2,4 @@
 # usage: scripts/lab/mk_variant.sh <name> [extra hipcc flags]  -> variants/libstmpc_<name>.so (an A/B or analysis build of the ABI)
 name=$1; shift
 mkdir -p variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -Iinclude "$@" rl-mpc-lanemerging_amd/csrc/stmpc.hip -o variants/libstmpc_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -Iinclude -DSTMPC_SRC_HASH=\"$(python -c 'import rl_mpc_lanemerging_amd as p; print(p.build.source_hash())')-$name\" "$@" rl-mpc-lanemerging_amd/csrc/stmpc.hip -o variants/libstmpc_$name.so

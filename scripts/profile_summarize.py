@@ -63,6 +63,14 @@ if os.path.exists(bl):
 open(os.path.join(rdir, tag + "_summary.txt"), "w").write("\n".join(lines) + "\n")
 mj = os.path.join(rdir, "measured.json")
 allm = json.load(open(mj)) if os.path.exists(mj) else {}
+# the sources the profiled library was built from (the same-run bench line carries the library's own hash): bench.py marks these
+# counters stale when the running library differs
+try:
+    meas["csrc_hash"] = json.loads(open(bl).read().strip().splitlines()[-1])["library"]["csrc_hash"]
+except Exception:
+    sys.path.insert(0, os.getcwd())
+    import rl_mpc_lanemerging_amd as _pkg
+    meas["csrc_hash"] = _pkg.build.source_hash()
 allm[workload] = meas
 json.dump(allm, open(mj, "w"), indent=1, sort_keys=True)
 print("\n".join(lines[:40])); print(json.dumps(meas, indent=1))

@@ -1,0 +1,137 @@
+"""BASELINE configs[3] at full size on ONE GPU, and the sharded path with the real solver in two processes.
+
+The 8-GPU run itself belongs to the driver; what can be proven here is (1) that solving 65536 H=40 episodes as the 8 shards of
+``sharding.shard_bounds`` gives the same bits as one launch over all of them (and the reference's, on a sample), and (2) that
+two ranks -- two processes, each with its own context, side stream and stream priorities, sharing device 0 -- solve their
+shards with the HIP solver concurrently and gather the right (action, cost) rows."""
+import json
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _h40_params():
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    return _capi.Params.from_settings(pkg.Settings)
+
+
+def test_config4_full_size_sharded_equals_single_launch(restore_settings):
+    """65536 episodes (H=40, S=7201, K=6): 8 shards of 8192 solved one after the other in one context == one launch of 65536,
+    bit for bit; every 256th episode against the oracle's heap Dijkstra (the reference's algorithm)."""
+    from rl_mpc_lanemerging_amd import _capi, sharding, st, synth
+    from oracle import st_oracle as orc
+    p = _h40_params()
+    H = _capi.num_t(p)
+    n, world = 65536, 8
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=4004)
+    ctx = _capi.Context(0)
+    keys = ("path_idx", "best_t", "cost", "crash")
+    parts, t_shards = [], []
+    for r in range(world):
+        lo, hi = sharding.shard_bounds(n, world, r)
+        assert hi - lo == 8192
+        res = st.solve_arrays(ego[lo:hi], kc[lo:hi], ox[lo:hi], ov[lo:hi], p, ctx)
+        t_shards.append(ctx.stats()["solve_ms"])
+        parts.append(res)
+    sharded = {k: np.concatenate([q[k] for q in parts]) for k in keys}
+    st.solve_arrays(ego, kc, ox, ov, p, ctx)                      # (first launch of this size allocates its scratch)
+    whole = st.solve_arrays(ego, kc, ox, ov, p, ctx)
+    t_whole = ctx.stats()["solve_ms"]
+    tiers = ctx.stats()
+    for k in keys:
+        assert np.array_equal(sharded[k], whole[k]), k
+    path, bt = whole["path_idx"], whole["best_t"]
+    valid = np.arange(H)[None, :] <= bt[:, None]
+    assert (path[:, 0] == 0).all() and ((path >= 0) == valid).all()
+    sel = np.arange(0, n, 256)
+    ref = orc.solve_batch(orc.OrcParams.from_dict(p.as_dict()), ego[sel], kc[sel], ox[sel], ov[sel], solver="heap", nthreads=8)
+    for k in keys:
+        assert np.array_equal(ref[k], whole[k][sel]), k
+    ctx.close()
+    rec = {"test": "config4_full_size", "episodes": n, "shards": world, "shard_solve_ms": t_shards, "shards_total_ms": float(sum(t_shards)),
+           "single_launch_ms": t_whole, "single_launch_solves_per_s": n / t_whole * 1e3, "first_window": int(tiers["fast_path"]),
+           "larger_window": int(tiers["fallback"]), "oracle_sample": int(len(sel)), "library": _capi.backend_info()}
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rec, open(os.path.join(out, "config4_full_size.json"), "w"), indent=1)
+    print(json.dumps(rec))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, n, seed, q):
+    """One rank: its own process and context on device 0, the real solver on its shard, gloo all-gather of (action, cost)."""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, sharding, st, synth
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=seed)     # the same global batch in every rank
+    ctx = _capi.Context(0)                                                  # both ranks share device 0 on purpose
+    kept = {}
+
+    def solve(e_, k_, x_, v_):
+        r = None
+        for _ in range(3):                                                  # several steps, so that the two processes' launches really interleave
+            r = st.solve_arrays(e_, k_, x_, v_, p, ctx)
+        ctx.check_error()
+        kept.update(r)
+        return r["path_idx"], r["cost"]
+
+    dist.barrier()
+    t0 = time.perf_counter()
+    act, cost = sharding.ShardedSolver(rank, world, solve).solve_global(ego, kc, ox, ov)
+    dt = time.perf_counter() - t0
+    lo, hi = sharding.shard_bounds(n, world, rank)
+    q.put((rank, act, cost, kept["path_idx"], kept["best_t"], lo, hi, dt, ctx.stats()["fallback"]))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_share_one_gpu_with_the_real_solver(restore_settings):
+    """Two ranks x 4096 H=40 episodes on device 0 at the same time (two contexts, two side streams at top priority, overflow queues consumed
+    while they fill, in two processes): every rank ends up with every episode's action and cost, equal to a single-process solve."""
+    import torch.multiprocessing as mp
+    from rl_mpc_lanemerging_amd import _capi, st, synth
+    world, n, seed = 2, 8192, 515
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank, args=(r, world, port, n, seed, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    p = _h40_params()
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=seed)
+    ctx = _capi.Context(0)
+    one = st.solve_arrays(ego, kc, ox, ov, p, ctx)
+    ctx.close()
+    overflowed = 0
+    for rank, act, cost, path, bt, lo, hi, dt, fb in res:
+        assert np.array_equal(act, one["path_idx"][:, 1]) and np.array_equal(cost, one["cost"]), rank      # the gathered rows of all ranks
+        assert np.array_equal(path, one["path_idx"][lo:hi]) and np.array_equal(bt, one["best_t"][lo:hi]), rank
+        overflowed += fb
+    assert overflowed > 0          # the second window's concurrent launch was exercised in both processes' mix
