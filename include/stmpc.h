@@ -375,6 +375,12 @@ int stmpc_probe_arith(stmpc_ctx *ctx, int op, const double *a, const double *b, 
  * *zl (may be NULL) receives RN(1/d - RN(1/d)).  Host-only, no context. */
 int stmpc_fastdiv2_check(double d, double *zl);
 
+/* Analysis entry (profiles/, scripts/lab/predict_time.py): the average time in ms of `reps` launches of the traffic-prediction kernel alone
+ * (prediction.py:22-105 + st.py:44-65 for the whole horizon) on DEVICE-resident states, Kmax <= 8.  mask 0: the whole kernel; 1: its serial
+ * recurrence only, after which the context's vehicle table is not valid -- solve again before reading results. */
+int stmpc_debug_predict_ms(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax, const double *d_ego, const int32_t *d_k,
+                           const double *d_other_x, const double *d_other_v, int reps, int mask, float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

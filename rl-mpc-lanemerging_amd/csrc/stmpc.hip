@@ -530,14 +530,14 @@ int latch_solver_error(stmpc_ctx *c) {
     return STMPC_OK;
 }
 
-int g_pred_dbg = 0;      // (analysis: parts of k_predict switched off for timing, stmpc_debug_predict_ms only)
+int g_pred_dbg = 0;      // (analysis: k_predict without its table rows, stmpc_debug_predict_ms only)
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
                     CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st,
                     unsigned *sticky = nullptr, const unsigned char *guide_tab = nullptr, int guide_imax = 0, int guide_D = 0, u16 *guide = nullptr) {
     constexpr int E = PredShape<KMAX>::E;          // episodes per wavefront (k_predict)
     int blocks = (N + E - 1) / E;
-    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(64), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky,
+    hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(128), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky,
                        guide_tab, guide_imax, guide_D, guide, g_pred_dbg);
 }
 
@@ -924,8 +924,8 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
     return STMPC_OK;
 }
 
-// Analysis entry: time k_predict alone (reps launches between two events) on device-resident states; mask switches parts of the kernel off
-// (1: no table rows, 2: ego treated as standing still, 4: no vehicle loop, 8: no guide loads).  With mask != 0 the table is NOT valid.
+// Analysis entry: time k_predict alone (reps launches between two events) on device-resident states; mask 1 = the recurrence only (no table
+// rows: the table is NOT valid afterwards).
 int stmpc_debug_predict_ms(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego, const int32_t *d_k, const double *d_ox,
                            const double *d_ov, int reps, int mask, float *ms_out) {
     if (!c || !ms_out || N <= 0 || Kmax <= 0 || Kmax > 8 || reps < 1) return fail(STMPC_EINVAL, "bad argument");
@@ -943,7 +943,7 @@ int stmpc_debug_predict_ms(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax,
     if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc;
     CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
     const bool have_guide = c->guide_ok && c->guide_tab.p;
-    g_pred_dbg = mask;
+    g_pred_dbg = mask & 1;
     for (int r = 0; r < reps + 2; ++r) {
         if (r == 2) HIPCHK(hipEventRecord(c->ev0, nullptr));
         launch_predict<8>(dp, N, Kmax, d_ego, d_k, d_ox, d_ov, tab, c->counters.as<unsigned>(), c->ubound.as<u64>(), nullptr, nullptr, nullptr, nullptr, nullptr,

@@ -235,41 +235,62 @@ struct CarTab {
     int    *num_s;    // [N]   S of the episode
 };
 
-// Episodes per wavefront of k_predict: the predictor recurrence of an episode is one lane's serial chain, everything else about
-// an episode is spread over the wavefront's 64 lanes.
-template <int KMAX> struct PredShape { static constexpr int E = KMAX <= 8 ? 4 : (KMAX <= 16 ? 2 : 1); };
+// k_predict: one workgroup of TWO wavefronts per E = 32 / KMAX episodes.
+//   wavefront 0  the predictor recurrence (prediction.py:22-105 applied H-1 times, st.py:42-43), one LANE PER VEHICLE: the only serial part of the
+//                path, and what the whole launch waits for.  A lone wavefront pays 3-5 ns per instruction whatever it does (measured:
+//                scripts/lab/exp/issue_latency.hip), so the layer's instruction count is what is minimised:
+//                * the follower rule (prediction.py:72-97) is a chain over the vehicles -- each reacts to its leader's NEW speed and position.
+//                  Every lane applies the rule to its own vehicle against its left neighbour's current values (one DPP shift) and the sweep is
+//                  repeated until no lane changes: the chain's unique solution, exact, after at most k sweeps and typically two (start:
+//                  everyone keeps its speed);
+//                * which vehicle takes the ego as its leader, and which vehicle the phantom ego tails in the next layer, are ballots;
+//                * get_ego_s of the predicted ego feeds two comparisons only: comparisons of the squared distance with precomputed doubles
+//                  (DevP::q_*), no square root; an ego that is told to stand still does not move, so the unit vector of prediction.py:49-54 is
+//                  formed only for a moving ego on the ramp; the ego's speed and acceleration are never read back, crash flag and vehicle
+//                  accelerations are not needed here.
+//                Lanes 32-63 repeat lanes 0-31 (a wavefront with half of its lanes disabled issues more slowly, same measurement).
+//   wavefront 1  follows one group of layers behind: the obstructing-vehicle list of st.py:44-65 for every (layer, vehicle) -- front / back edge,
+//                blocked index window, the break / continue rules as ballots over the layer's lanes, entries compacted in vehicle order, one table
+//                row per lane group (coalesced) -- and the guide's cell of the layer checked against each listed vehicle.
+// (Round 3 ran all of it as one thread per episode: 119 us of serial prefix per step of 4096 episodes.)
+template <int KMAX> struct PredShape { static constexpr int E = 32 / KMAX; };
 
-// k_predict: one WAVEFRONT per E episodes, two phases.
-//   1  lanes 0..E-1: the predictor recurrence of their episode (prediction.py:22-105 applied H-1 times, st.py:42-43) -- the only part that is
-//      serial (layer after layer, vehicle after vehicle); the vehicles' positions of every layer go to LDS, and so do the cells of the guide.
-//   2  all lanes: one (layer, vehicle) pair each, KMAX lanes per layer: the obstructing-vehicle list of st.py:44-65 -- front / back edge, blocked
-//      index window, the break / continue rules as a ballot over the layer's lanes, entries compacted in vehicle order -- written with one
-//      row of the table per lane group (coalesced), and the guide's cell of the layer checked against each listed vehicle.
-// (Round 3 ran all of it as one thread per episode: 64 wavefronts for 4096 episodes, each store instruction touching 64 table rows 5 KB
-// apart; 119 us of serial prefix per step.)
+// lane i <- lane i-1 within an aligned group of GL lanes (the group's first lane gets something it never uses): a DPP row shift where
+// the group lies within a 16-lane row, else a permute through the LDS crossbar
+template <int GL>
+__device__ __forceinline__ double left_neighbour(double v, int lane) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (GL <= 16)
+        return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false));
+    else
+        return __shfl(v, lane > 0 ? lane - 1 : 0, 64);
+}
+
 template <int KMAX>
-__global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const double *__restrict__ ego,
-                                                const int *__restrict__ k_count,
-                                                const double *__restrict__ other_x,
-                                                const double *__restrict__ other_v, CarTab tab,
-                                                unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */,
-                                                int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */,
-                                                unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */,
-                                                int *resume_t /* [N] or null: zeroed here */,
-                                                unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */,
-                                                unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */,
-                                                const unsigned char *__restrict__ guide_tab /* [(imax+1)*(2D+1)][H-1] steps of the unobstructed optimum, or null */,
-                                                int guide_imax, int guide_D, u16 *guide /* [N][H] out */, int dbg = 0) {
+__global__ void __launch_bounds__(128) k_predict(DevP p, int N, int Kmax, const double *__restrict__ ego,
+                                                 const int *__restrict__ k_count,
+                                                 const double *__restrict__ other_x,
+                                                 const double *__restrict__ other_v, CarTab tab,
+                                                 unsigned *counters /* [64], zeroed here */, u64 *ubound /* [N] or null, zeroed here */,
+                                                 int *queue1 /* [N] or null: first overflow queue, preset to -1 (empty slots) */,
+                                                 unsigned *proxy0 /* [N] or null: zeroed here (split tasks) */,
+                                                 int *resume_t /* [N] or null: zeroed here */,
+                                                 unsigned char *prio_key /* [N] or null: static weight class of the episode, 0 = heaviest */,
+                                                 unsigned *sticky /* [2] or null: error flags that survive until stmpc_check_error reads them */,
+                                                 const unsigned char *__restrict__ guide_tab /* [(imax+1)*(2D+1)][H-1] steps of the unobstructed optimum, or null */,
+                                                 int guide_imax, int guide_D, u16 *guide /* [N][H] out */, int recurrence_only = 0 /* analysis: no table rows */) {
+    static_assert(KMAX == 8 || KMAX == 16 || KMAX == 32, "lanes per episode");
     constexpr int E = PredShape<KMAX>::E;
-    constexpr int LPI = 64 / KMAX;                       // layers per iteration of phase 2
-    __shared__ double xs_l[E][STMPC_MAXH][KMAX];         // vehicle positions per layer (phase 1 -> phase 2)
+    constexpr int LPI = 64 / KMAX;                       // layers per sweep of wavefront 1
+    __shared__ double xs_l[E][STMPC_MAXH][KMAX];         // vehicle positions per layer (wavefront 0 -> wavefront 1)
     __shared__ double unc_l[STMPC_MAXH];
     __shared__ int dunc_l[STMPC_MAXH];
     __shared__ double ep_start[E], ep_slast[E];
-    __shared__ int ep_S[E], ep_k[E], gbad_l[E];
+    __shared__ int ep_S[E], ep_k[E], gok_l[E];
     __shared__ int gcell_l[E][STMPC_MAXH];
-    const int lane = threadIdx.x;
-    const int g = blockIdx.x * 64 + lane;                // (the grid has at least N threads)
+    __shared__ int prog;                                 // layers whose positions are in xs_l
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x * 128 + tid;                // (the grid has at least N threads)
     // the previous solve's error flag is latched before the counters are reused (same wavefront: the read precedes lane 63's store)
     if (g == 0 && sticky && counters[63 /* STMPC_CNT_ERR */]) atomicOr(&sticky[0], 1u);
     if (g < 64) counters[g] = 0u;
@@ -279,58 +300,49 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
         if (proxy0) proxy0[g] = 0u;
         if (resume_t) resume_t[g] = 0;
     }
-    if (lane < p.H) { unc_l[lane] = p.unc[lane]; dunc_l[lane] = p.dunc[lane]; }
+    if (tid < p.H) { unc_l[tid] = p.unc[tid]; dunc_l[tid] = p.dunc[tid]; }
+    if (tid == 0) prog = 0;
     const int e0 = blockIdx.x * E;
-    bool g_ok = false;
-    if (lane < E) { gbad_l[lane] = 0; ep_k[lane] = 0; ep_S[lane] = 0; }
-    // ---- phase 1: the recurrence (lanes 0..E-1).
-    // prediction.py:22-105 restated for this use: H-1 applications of predict_step_without_ego on its own output, of which only the vehicles'
-    // positions are kept.  What that allows (same bits in every position): the ego's speed and acceleration are never read back; the crash flag
-    // and the per-vehicle accelerations are not needed; get_ego_s of the predicted ego feeds two comparisons only, which are comparisons of the
-    // squared distance with precomputed doubles (DevP::q_*); an ego that is told to stand still does not move, so the unit vector of
-    // prediction.py:49-54 is formed only for a moving ego on the ramp; and the search for the vehicle the phantom ego tails in the NEXT
-    // layer (prediction.py:28-40: compares the vehicles' new positions with the ego's new position) rides along the follower loop.
-    // The code is branch-free apart from wave-uniform tests: the lanes' serial chain is what the whole launch waits for.
-    // (every lane runs the recurrence of episode e0 + (lane mod E): 64 / E identical copies, of which the first writes.  Measured on gfx950
-    // (scripts/lab/exp/issue_latency.hip): a wavefront with 4 of its 64 lanes enabled issues independent fp64 operations 3.7 times more slowly
-    // than the same wavefront with all lanes enabled)
-    const int pl = lane & (E - 1);
-    const bool wr = lane < E;
-    int k = 0;
-    if (e0 + pl < N) {
-        k = k_count[e0 + pl];
+    // ---- both wavefronts: per-episode constants (wavefront 0 keeps them in registers, wavefront 1 reads them from LDS)
+    const int l32 = lane & 31;
+    const int el0 = l32 / KMAX, c0 = l32 & (KMAX - 1);
+    int k = 0, S = 0;
+    double start_s = 0.0, delta = 1.0, ex = 0.0, ey = 0.0, ev0 = 0.0, ea0 = 0.0;
+    const bool live = e0 + el0 < N;
+    if (live) {
+        const int e = e0 + el0;
+        ex = ego[e * 5 + 0]; ey = ego[e * 5 + 1]; ev0 = ego[e * 5 + 2]; ea0 = ego[e * 5 + 3]; start_s = ego[e * 5 + 4];
+        k = k_count[e];
         k = k < 0 ? 0 : (k > KMAX ? KMAX : k);
         k = k > Kmax ? Kmax : k;                 // the table rows hold Kmax entries (device-pointer callers are not validated on the host)
-    }
-    const int kw = wave_max_i(k);                // most vehicles of any of the wavefront's episodes (a DPP reduction: all lanes take part)
-    if (e0 + pl < N) {
-        const int e = e0 + pl;
-        double ex = ego[e * 5 + 0], ey = ego[e * 5 + 1];
-        const double ev0 = ego[e * 5 + 2], ea0 = ego[e * 5 + 3];
-        const double start_s = ego[e * 5 + 4];
-        double xs[KMAX], vs[KMAX];
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) {
-            bool in = (i < k) && (i < Kmax);
-            xs[i] = in ? other_x[(size_t)e * Kmax + i] : 0.0;
-            vs[i] = in ? other_v[(size_t)e * Kmax + i] : 0.0;
+        S = dev_num_s(p, start_s);
+        const double s1 = start_s + p.ds;        // s_values[S-1] per numpy's arange fill
+        delta = s1 - start_s;
+        if (wave == 0 && lane < 32 && c0 == 0) {
+            tab.num_s[e] = S;
+            ep_start[el0] = start_s;
+            ep_slast[el0] = (S - 1 == 1) ? s1 : start_s + (double)(S - 1) * delta;
+            ep_S[el0] = S; ep_k[el0] = k;
         }
-        const int S = dev_num_s(p, start_s);
-        if (wr) tab.num_s[e] = S;
-        // s_values[S-1] per numpy's arange fill
-        const double s1 = start_s + p.ds;
-        const double delta = s1 - start_s;
-        if (wr) {
-            ep_start[pl] = start_s;
-            ep_slast[pl] = (S - 1 == 1) ? s1 : start_s + (double)(S - 1) * delta;
-            ep_S[pl] = S; ep_k[pl] = k;
-        }
+    } else if (wave == 0 && lane < 32 && c0 == 0) { ep_S[el0] = 0; ep_k[el0] = 0; ep_start[el0] = 0.0; ep_slast[el0] = 0.0; gok_l[el0] = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        // ================= wavefront 0: the recurrence, lane = (episode el0, vehicle c0) =================
+        const int c = c0, el = el0;
+        const int grp = lane & ~(KMAX - 1);
+        const u64 gmask = (1ull << KMAX) - 1ull;
+        const bool wr = lane < 32 && live;
+        const bool in = c < k;
+        double x = 0.0, v = 0.0;
+        if (live && in && c < Kmax) { x = other_x[(size_t)(e0 + el) * Kmax + c]; v = other_v[(size_t)(e0 + el) * Kmax + c]; }
+        const int kw = wave_max_i(k);                // most vehicles of any of the wavefront's episodes: sweeps that settle every chain
         // Guide of the guided bounding attempt (SolveArgs::guide): the unobstructed optimum from the lattice state nearest to the episode's start
         // (cells covered per layer at the start speed, and one layer earlier), usable if it stays on the lattice and clear of every vehicle and of
-        // its penalty zone (checked in phase 2).  Approximate on purpose: it only centres a search whose result is checked like any other bound.
+        // its penalty zone (checked by wavefront 1).  Approximate on purpose: it only centres a search whose result is checked like any other bound.
         const unsigned char *grow = nullptr;
         int g_cell = 0;
-        if (guide_tab) {
+        bool g_ok = false;
+        if (guide_tab && live) {
             const double cps = p.dt / delta;
             int i1 = (int)rint(ev0 * cps), i2 = (int)rint((ev0 - ea0 * p.dt) * cps);
             i1 = i1 < 0 ? 0 : (i1 > guide_imax ? guide_imax : i1);
@@ -340,58 +352,55 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
             grow = guide_tab + ((size_t)i1 * (2 * guide_D + 1) + (size_t)(d + guide_D)) * (size_t)(p.H - 1);
             g_ok = true;
         }
-        if (prio_key && wr) {
+        if (prio_key && wr && c == 0) {
             // the slower the ego starts, the more of the lattice stays below the cost bound (rank correlation of the exact pass's
             // time with the start speed: -0.57 on the benchmark states)
             double f = ev0 / (p.v_max > 0.0 ? p.v_max : 1.0);
             f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
-            prio_key[e] = (unsigned char)(f * 255.0);
+            prio_key[e0 + el] = (unsigned char)(f * 255.0);
         }
         // The loop's launch constants, made opaque so that they stay in registers: left to itself the compiler re-loads them from the kernel
-        // argument segment inside the loop (DevP is large), and a scalar load + wait in a lone wavefront's serial chain costs hundreds of cycles.
+        // argument segment inside the loop (DevP is large), and a scalar load + wait in the serial chain costs hundreds of cycles.
         double c_carlen = p.car_length, c_thr = p.react_thr, c_qgn = p.q_gt_neg, c_qgp = p.q_gt_pos, c_qln = p.q_lt_neg, c_qlp = p.q_lt_pos;
         double c_dt = p.dt, c_gap = p.follow_gap, c_dcl = p.max_pred_decel;
         int c_H = p.H;
         asm volatile("" : "+s"(c_carlen), "+s"(c_thr), "+s"(c_qgn), "+s"(c_qgp), "+s"(c_qln), "+s"(c_qlp), "+s"(c_dt), "+s"(c_gap), "+s"(c_dcl), "+s"(c_H));
-        if (dbg & 16) c_H = 1;
         const bool dcl_nonpos = c_dcl <= 0.0;
         // control.py:373-380 of a position as the two comparisons with react_thr that prediction.py makes (x*x for the squares, as dev_ego_s);
         // straight-line mask logic, no short-circuit branches
         const double mpx = -50.9, mpy = 1.72, mp2x = 1.5, mp2y = -1.5, mp3x = -51.0;
         const double common_s = mp2x - mp3x;
-        auto zone = [&](double x, double y, bool &gt, bool &lt) {
-            const double dx = x - mpx, dy = y - mpy;
+        auto zone = [&](double zx, double zy, bool &gt, bool &lt) {
+            const double dx = zx - mpx, dy = zy - mpy;
             const double q = dx * dx + dy * dy;
-            const double lin = x - mp2x + common_s;
-            const bool neg = x < mpx, pos = x < mp2x;                       // (neg implies pos)
+            const double lin = zx - mp2x + common_s;
+            const bool neg = zx < mpx, pos = zx < mp2x;                     // (neg implies pos)
             const bool mid = pos & !neg, hwy = !pos;
             gt = (neg & (q < c_qgn)) | (mid & (q > c_qgp)) | (hwy & (lin > c_thr));
             lt = (neg & (q > c_qln)) | (mid & (q < c_qlp)) | (hwy & (lin < c_thr));
         };
-        // what predict_step_without_ego will decide from a state (prediction.py:24-44): stand still / park / tail the vehicle ahead of the first one behind
-        bool lt, gt_unused;
-        zone(ex, ey, gt_unused, lt);
-        bool found = false;                      // some vehicle is behind the ego
-        double lx = 0.0, lv = 0.0;               // position and speed of the last vehicle that is not (before the first one that is)
-#pragma unroll
-        for (int i = 0; i < KMAX; ++i) {
-            const bool in = i < k;
-            const bool b = xs[i] < ex;
-            const bool take = in && !found && !b;
-            lx = take ? xs[i] : lx; lv = take ? vs[i] : lv;
-            found = found || (in && b);
-        }
-        bool park = k > 0 && xs[0] < ex;         // prediction.py:28
-#pragma unroll
-        for (int c = 0; c < KMAX; ++c) if (wr) xs_l[pl][0][c] = xs[c];
-        if (wr) gcell_l[pl][0] = 0;
+        // What predict_step_without_ego decides from a state (prediction.py:24-44): stand still / park / tail the vehicle ahead of the first one
+        // that is behind the ego.  A ballot over the episode's lanes: is anyone behind, is the front vehicle behind, who is the first.
+        bool lt, found, park;
+        double lx, lv;                           // position and speed of the vehicle to tail (the last one if nobody is behind)
+        auto who_is_behind = [&](double egox) {
+            const u64 m = (__ballot(in && x < egox) >> grp) & gmask;
+            found = m != 0ull;
+            park = (m & 1ull) != 0ull;                                      // prediction.py:28 (the front vehicle; k > 0 is part of `in`)
+            const int fb = found ? __ffsll((long long)m) - 1 : k;           // first vehicle behind, or one past the last
+            const int src = grp + (fb > 0 ? fb - 1 : 0);
+            lx = __shfl(x, src, 64); lv = __shfl(v, src, 64);
+        };
+        { bool gt_unused; zone(ex, ey, gt_unused, lt); }
+        who_is_behind(ex);
+        if (wr) xs_l[el][0][c] = x;
+        if (wr && c == 0) gcell_l[el][0] = 0;
         int g_next = grow ? (int)grow[0] : 0;          // the row's steps are fetched one layer ahead: the load's latency hides behind the layer's work
         for (int t = 1; t < c_H; ++t) {
             // -- predict_step_without_ego's choice (prediction.py:24-44)
             const bool still = lt || k == 0;
             const bool tail = !still && !park;
             double sel = 0.0;
-            if (dbg & 2) { lt = true; }
             if (!still && park) { ex = -20.0; ey = -10.0; }
             if (tail) { if (found) ex = lx - c_carlen - 5; sel = lv; }
             // -- the ego's step (prediction.py:47-59).  An ego that stands still keeps its position bit for bit: cx + (d0 / nrm) * (0 * dt) = cx.
@@ -413,78 +422,69 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
             if (ramp && py < -1.6) py = -1.6;
             bool merged;
             zone(px, py, merged, lt);                  // prediction.py:64-66 (and the next layer's prediction.py:24)
-            // -- the vehicles, front to back (prediction.py:72-97), and the next layer's search for the vehicle to tail.
-            // The loop-carried chain (leader's new speed and position -> this vehicle's) is kept to VALU operations without mask round trips:
-            // which vehicle takes the ego as its leader depends on the OLD positions only and is settled before the loop, and
-            //   nv = ov + acc * dt,  acc = (sd < 0 && xd < gap) ? max(sd, decel) : 0        (prediction.py:83-91; ov + 0 * dt = ov)
-            // with max(sd, decel) for sd < 0, else 0, as min(max(sd, decel), 0).
-            bool lead_ego[KMAX];
-            {
-                bool enc = false;
-#pragma unroll
-                for (int i = 0; i < KMAX; ++i) {
-                    const bool first_behind = xs[i] < px && !enc;                   // prediction.py:78-82
-                    enc = enc || first_behind;
-                    lead_ego[i] = first_behind && merged;
-                }
+            // -- the vehicles (prediction.py:72-97).  Leader of the front vehicle: nobody (inf, 0); of the first vehicle behind the ego, once
+            // the ego has merged: the ego (prediction.py:78-82, old positions against the ego's new one); of everyone else: the left neighbour.
+            const u64 mo = (__ballot(in && x < px) >> grp) & gmask;
+            const bool lead_ego = merged && mo != 0ull && c == __ffsll((long long)mo) - 1;
+            const bool fixed = c == 0 || lead_ego;
+            const double fix_x = lead_ego ? px : __builtin_inf(), fix_v = lead_ego ? sel : 0.0;
+            //   nv = ov + acc * dt,  acc = (sd < 0 && xd < gap) ? max(sd, decel) : 0   (prediction.py:83-91; ov + 0 * dt = ov), the maximum for
+            //   sd < 0 and else 0 taken as min(max(sd, decel), 0) for the usual decel <= 0
+            double gv = v, gx = x + v * c_dt;                                      // first guess: everyone keeps its speed
+            for (int sweep = 0; sweep < kw; ++sweep) {
+                const double nbx = left_neighbour<KMAX>(gx, lane), nbv = left_neighbour<KMAX>(gv, lane);
+                const double Lx = fixed ? fix_x : nbx, Lv = fixed ? fix_v : nbv;
+                const double sd = Lv - v, xd = Lx - x;
+                double acc = __builtin_fmin(__builtin_fmax(sd, c_dcl), 0.0);
+                if (!dcl_nonpos) acc = (sd < 0) ? dmax_py(sd, c_dcl) : 0.0;      // (launch-uniform: a positive "deceleration" takes the literal form)
+                acc = (xd < c_gap) ? acc : 0.0;
+                const double nv = v + acc * c_dt;
+                const double nx = x + nv * c_dt;
+                const bool changed = in && (nx != gx || nv != gv);
+                gx = nx; gv = nv;
+                if (__ballot(changed) == 0ull) break;                              // every lane reproduced its value from settled leaders
             }
-            double last_x = __builtin_inf(), last_speed = 0.0;
-            found = false; lx = 0.0; lv = 0.0;
-#pragma unroll
-            for (int i = 0; i < KMAX; ++i) {
-                if (i < kw && !(dbg & 4)) {                                                      // (wave-uniform)
-                    const double ov = vs[i], ox = xs[i];
-                    last_x = lead_ego[i] ? px : last_x; last_speed = lead_ego[i] ? sel : last_speed;
-                    const double sd = last_speed - ov;
-                    const double xd = last_x - ox;
-                    double acc = __builtin_fmin(__builtin_fmax(sd, c_dcl), 0.0);
-                    if (!dcl_nonpos) acc = (sd < 0) ? dmax_py(sd, c_dcl) : 0.0;      // (launch-uniform: a positive "deceleration" takes the literal form)
-                    acc = (xd < c_gap) ? acc : 0.0;
-                    const double nv = ov + acc * c_dt;
-                    const double nx = ox + nv * c_dt;
-                    last_x = nx; last_speed = nv;
-                    xs[i] = nx; vs[i] = nv;
-                    const bool in = i < k;
-                    const bool b = nx < px;
-                    const bool take = in && !found && !b;
-                    lx = take ? nx : lx; lv = take ? nv : lv;
-                    found = found || (in && b);
-                }
-            }
-            park = k > 0 && xs[0] < px;
+            x = gx; v = gv;
             ex = px; ey = py;
-            if (wr) {
-#pragma unroll
-                for (int c = 0; c < KMAX; ++c) xs_l[pl][t][c] = xs[c];
-            }
+            who_is_behind(px);                         // the next layer's prediction.py:28-40, on the new positions
+            if (wr) xs_l[el][t][c] = x;
             if (grow) {
                 const int stp = g_next;
-                if (t < c_H - 1 && !(dbg & 8)) g_next = (int)grow[t];
+                if (t < c_H - 1) g_next = (int)grow[t];
                 g_ok = g_ok && stp != 255;
                 g_cell += stp;
                 g_ok = g_ok && g_cell < S;
             }
-            if (wr) gcell_l[pl][t] = g_cell;
+            if (wr && c == 0) gcell_l[el][t] = g_cell;
+            if ((t & (LPI - 1)) == LPI - 1 && lane == 0) __hip_atomic_store(&prog, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (wr && c == 0) gok_l[el] = g_ok ? 1 : 0;
+        if (lane == 0) __hip_atomic_store(&prog, c_H, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
     }
-    __syncthreads();
-    // ---- phase 2: the obstructing-vehicle list of every layer, KMAX lanes per layer
+    // ================= wavefront 1: the obstructing-vehicle list of every layer, KMAX lanes per layer =================
+    if (recurrence_only) return;
     const int c = lane & (KMAX - 1);
     const int grp = lane & ~(KMAX - 1);
     const u64 gmask = KMAX >= 64 ? ~0ull : ((1ull << KMAX) - 1ull);
-    for (int el = 0; el < E; ++el) {
-        const int e = e0 + el;
-        if (e >= N || (dbg & 1)) break;                                                         // (wave-uniform)
-        const int k = ep_k[el], S = ep_S[el];
-        const double start_s = ep_start[el], s_last = ep_slast[el];
-        const double delta = (start_s + p.ds) - start_s;
-        bool bad = false;
-        for (int tb = 0; tb < p.H; tb += LPI) {
-            const int t = tb + (lane / KMAX);
-            const bool tin = t < p.H;
-            const int tt = tin ? t : 0;
+    bool bad[E];
+#pragma unroll
+    for (int el = 0; el < E; ++el) bad[el] = false;
+    for (int tb = 0; tb < p.H; tb += LPI) {
+        const int need = tb + LPI < p.H ? tb + LPI : p.H;
+        while (__hip_atomic_load(&prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(8);
+        const int t = tb + (lane / KMAX);
+        const bool tin = t < p.H;
+        const int tt = tin ? t : 0;
+#pragma unroll
+        for (int el = 0; el < E; ++el) {
+            const int e = e0 + el;
+            if (e >= N) break;                                                     // (wave-uniform)
+            const int ke = ep_k[el], Se = ep_S[el];
+            const double st_s = ep_start[el], s_last = ep_slast[el];
+            const double dl = (st_s + p.ds) - st_s;
             const double o = xs_l[el][tt][c] - (-51.0);                            // control.py:388-389
-            const bool inb = tin && c < k;
+            const bool inb = tin && c < ke;
             const bool below = inb && o < p.obst_min_s;                            // st.py:46-47 break: this vehicle and every later one
             const u64 bm = (__ballot(below) >> grp) & gmask;
             const bool stop = (bm & ((2ull << c) - 1ull)) != 0ull;
@@ -497,19 +497,19 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                 const int dunc = dunc_l[tt];
                 const double front = o - p.car_length - unc;
                 const double back = o + p.car_length + unc;
-                const int i0 = (int)((o - start_s) / p.ds);                        // st.py:60 (trunc toward 0)
+                const int i0 = (int)((o - st_s) / p.ds);                           // st.py:60 (trunc toward 0)
                 int imin = i0 - p.dlen - dunc; imin = imin < 0 ? 0 : imin;
-                int imax = i0 + p.dlen + dunc; imax = imax > S ? S : imax;
-                if (!(imin < S && imax > 0)) { imin = 0; imax = 0; }               // st.py:63
+                int imax = i0 + p.dlen + dunc; imax = imax > Se ? Se : imax;
+                if (!(imin < Se && imax > 0)) { imin = 0; imax = 0; }              // st.py:63
                 double2 ed; ed.x = front; ed.y = back;
                 int2 wd; wd.x = imin; wd.y = imax;
                 *(double2 *)&tab.edge[(rowbase + slot) * 2] = ed;
                 *(int2 *)&tab.win[(rowbase + slot) * 2] = wd;
                 if (guide_tab && tt != 0) {                                        // the guide's cell of this layer against this vehicle
-                    const int g_cell = gcell_l[el][tt];
-                    const double g_sn = start_s + (double)g_cell * delta;
+                    const int gc = gcell_l[el][tt];
+                    const double g_sn = st_s + (double)gc * dl;
                     const double gd = __builtin_fmin(fabs(g_sn - front), fabs(g_sn - back));
-                    if ((g_cell >= imin && g_cell < imax) || gd < p.min_allowed) bad = true;
+                    if ((gc >= imin && gc < imax) || gd < p.min_allowed) bad[el] = true;
                 }
             }
             if (tin && c == 0) {
@@ -517,16 +517,20 @@ __global__ void __launch_bounds__(64) k_predict(DevP p, int N, int Kmax, const d
                 if (guide_tab && tt != 0) { const int gc = gcell_l[el][tt]; guide[(size_t)e * p.H + tt] = (u16)(gc < 65535 ? gc : 65535); }
             }
         }
-        if (__ballot(bad) != 0ull && lane == 0) gbad_l[el] = 1;
     }
-    __syncthreads();
-    if (lane < E && e0 + lane < N && guide_tab) {
-        const int e = e0 + lane;
-        g_ok = g_ok && gbad_l[lane] == 0;
-        guide[(size_t)e * p.H] = g_ok ? (u16)0 : (u16)0xffff;
-        // Episodes whose unobstructed optimum is clear of the traffic behave: their bounds are tight, their exact passes do not overflow the window (offline:
-        // none of 245).  The others hold every long chain of a step (poor bound -> wide search -> window overflow -> second window), so they go first.
-        if (prio_key) prio_key[e] = (unsigned char)((g_ok ? 128 : 0) + (prio_key[e] >> 1));
+    // (prog == H: wavefront 0 has written gok_l)
+#pragma unroll
+    for (int el = 0; el < E; ++el) {
+        const int e = e0 + el;
+        if (e >= N || !guide_tab) break;
+        const bool anybad = __ballot(bad[el]) != 0ull;
+        if (lane == 0) {
+            const bool ok = gok_l[el] != 0 && !anybad;
+            guide[(size_t)e * p.H] = ok ? (u16)0 : (u16)0xffff;
+            // Episodes whose unobstructed optimum is clear of the traffic behave: their bounds are tight, their exact passes do not overflow the window (offline:
+            // none of 245).  The others hold every long chain of a step (poor bound -> wide search -> window overflow -> second window), so they go first.
+            if (prio_key) prio_key[e] = (unsigned char)((ok ? 128 : 0) + (prio_key[e] >> 1));
+        }
     }
 }
 

@@ -14,8 +14,7 @@ dev = torch.device("cuda", 0)
 d = [torch.as_tensor(a, device=dev) for a in (ego, k, ox, ov)]
 lib = _capi.load()
 lib.stmpc_debug_predict_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.POINTER(C.c_float)]
-for mask, what in ((0, "whole kernel"), (1, "no table rows (phase 1 only)"), (9, "phase 1 without guide loads"), (3, "phase 1, ego standing still"), (5, "phase 1 without the vehicle loop"),
-                   (7, "phase 1: neither"), (15, "loop skeleton"), (6, "phase 2 + skeleton"), (31, "no loop at all, no phase 2 (fixed part)"), (30, "fixed part + phase 2 on layer 0 only")):
+for mask, what in ((0, "whole kernel"), (1, "recurrence only (no table rows)")):
     ms = C.c_float(0)
     rc = lib.stmpc_debug_predict_ms(ctx._h, C.byref(p), n, 8, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 20, mask, C.byref(ms))
     print("mask %2d  %-40s rc %d  %.1f us" % (mask, what, rc, ms.value * 1e3))

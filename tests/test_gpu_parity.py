@@ -549,3 +549,44 @@ def test_random_parameter_sets_large_batches(seed, restore_settings):
     ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=32)
     _check(res, ref, _capi.num_t(p))
     ctx.close()
+
+
+@pytest.mark.parametrize("kmax", [8, 12, 20])
+def test_horizon_prediction_matches_oracle_on_merge_zone_states(kmax, gpu_ctx, restore_settings):
+    """k_predict's recurrence (one lane per vehicle, leader chains settled by repeated sweeps, squared-distance thresholds, the ego's
+    curved step only where it moves) against the oracle's predictor applied H-1 times (prediction.py:22-105 -> st.py:25-70): the
+    materialised grids of 150 states per width that put the phantom ego through every branch -- on the ramp before and after the
+    reaction threshold, beside and between vehicles, ahead of all of them, stopped leaders (long deceleration chains), vehicles that
+    overtake the ego's position, states at the ramp's end point and at the merge point -- bit for bit, for 8-, 16- and 32-lane groups."""
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    p = _capi.Params.from_settings(pkg.Settings)
+    op = orc.OrcParams.from_dict(p.as_dict())
+    rng = np.random.default_rng(900 + kmax)
+    checked = curved = 0
+    for i in range(150):
+        mode = i % 6
+        ex = [rng.uniform(-75, -40), rng.uniform(-51.2, -50.6), rng.uniform(-45, 1.4), rng.uniform(1.3, 1.7), rng.uniform(1.5, 40), rng.uniform(-250, 60)][mode]
+        ey = (1.72 + 0.134 * (-50.9 - ex)) if ex < -50.9 else ((1.71 + (ex + 50.9) / 52.4 * (-1.6 - 1.71)) if ex < 1.5 else -1.6)
+        ey += rng.uniform(-0.05, 0.05) if i % 4 == 0 else 0.0
+        k = int(rng.integers(0, kmax + 1)) if i % 7 else kmax
+        lead = ex + rng.uniform(-30, 70)
+        gaps = rng.uniform(4.0, 28.0, size=max(k, 1))
+        xs = (lead - np.concatenate([[0.0], np.cumsum(gaps[:-1])]))[:k]
+        vs = rng.choice([7.0, 11.0, 15.0], size=1) + rng.choice([0.0, 0.0, -1.0, -4.0, 2.5], size=k)
+        if i % 5 == 0 and k:
+            vs[int(rng.integers(0, k))] = 0.0                              # a stopped vehicle: everyone behind it brakes in turn
+        vs = np.maximum(vs, 0.0)
+        ev, ea = rng.uniform(0, 25), rng.uniform(-3, 3)
+        start_s = _capi.ego_s(ex, ey)
+        ob, sv, tv, di = gpu_ctx.build_grid(p, [ex, ey, ev, ea, start_s], xs, vs)
+        st_ = orc.make_state(ex, ey, ev, ea, list(xs), list(vs))
+        rob, rsv, rtv, rdi = orc.build_grid(op, st_, start_s)
+        assert np.array_equal(ob, rob), (i, mode)
+        assert np.array_equal(di, rdi), (i, mode)
+        assert np.array_equal(sv, rsv)
+        checked += 1
+        curved += int(-45 < ex < 1.5)
+    assert checked == 150 and curved > 20
