@@ -90,6 +90,39 @@ struct DevP {
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ double dmin_py(double a, double b) { return (b < a) ? b : a; }   // Python/Cython min(a,b)
 __device__ __forceinline__ double dmax_py(double a, double b) { return (b > a) ? b : a; }   // Python/Cython max(a,b)
+// The same for operands that are never NaN, as ONE v_min_f64 / v_max_f64 instead of compare + two selects + constant moves: equal to
+// Python's min / max except for the sign of a zero result, which no consumer here can see (it is multiplied by dt and added to a coordinate).
+__device__ __forceinline__ double dmin1(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax1(double a, double b) { return __builtin_fmax(a, b); }
+
+// Edge cost of st_cy.pyx:46-50 without its gap term, as a function of the candidate's offset u = s_n - s from the source (metres):
+//   k_v (u - A)^2 + k_a (u - d1)^2 + k_j (u - (2 d1 - d2))^2,   A = v_des dt,  d1 = s - s_1,  d2 = s_1 - s_2
+// = K (u - m)^2 + emin with  m = (k_v A + (k_a + 2 k_j) d1 - k_j d2) / K  and  emin = k_v A^2 + k_a d1^2 + k_j (2 d1 - d2)^2 - K m^2.
+// Used by the candidate filters only (never for a cost that is output): FMAs are fine here.
+struct EdgeQuad {
+    double kv, ka, kj, K, invK, w0, w1, w2, kvA2;
+    bool ok;            // the cost has a quadratic part (K > 0)
+};
+__device__ __forceinline__ EdgeQuad edge_quad(const DevP &p) {
+    EdgeQuad q;
+    q.kv = p.v_w / p.dt2; q.ka = p.a_w / (p.dt2 * p.dt2); q.kj = p.j_w / (p.dt3 * p.dt3);
+    q.K = q.kv + q.ka + q.kj;
+    q.invK = 1.0 / q.K;
+    q.ok = q.K > 0.0 && q.invK < 1e300;
+    const double A = p.v_des * p.dt;
+    q.w0 = q.kv * A * q.invK; q.w1 = (q.ka + 2.0 * q.kj) * q.invK; q.w2 = -q.kj * q.invK;
+    q.kvA2 = q.kv * A * A;
+    return q;
+}
+// m and emin of a source; *mag receives t + K m^2 (the magnitude the cancellation in emin is relative to)
+__device__ __forceinline__ void edge_quad_source(const EdgeQuad &q, double d1, double d2, double &m, double &emin, double *mag = nullptr) {
+    const double cj = __builtin_fma(2.0, d1, -d2);
+    m = __builtin_fma(q.w1, d1, __builtin_fma(q.w2, d2, q.w0));
+    const double t = __builtin_fma(q.kj * cj, cj, __builtin_fma(q.ka * d1, d1, q.kvA2));
+    const double km2 = q.K * m * m;
+    emin = t - km2;
+    if (mag) *mag = t + km2;
+}
 
 // Wave-wide integer min / max on the DPP network (no LDS round trips): row_shr 1,2,4,8 leave each
 // 16-lane row's result in its last lane, row_bcast:15 / row_bcast:31 fold the rows, lane 63 holds the result.
@@ -867,11 +900,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
     };
     u16 *bp = ep.bp;
-    struct { double kv, ka, kj, invK, K; bool ok; } nk;     // coefficients of the edge-cost quadratic (see the candidate filter)
-    nk.kv = p.v_w / dt2; nk.ka = p.a_w / (dt2 * dt2); nk.kj = p.j_w / (dt3 * dt3);
-    nk.K = nk.kv + nk.ka + nk.kj;
-    nk.invK = 1.0 / nk.K;
-    nk.ok = (nk.kv + nk.ka + nk.kj) > 0.0 && nk.invK < 1e300;      // no filter when the cost has no quadratic part
+    const EdgeQuad nk = edge_quad(p);     // coefficients of the edge-cost quadratic (see the candidate filter); no filter when the cost has no quadratic part
 
     STMPC_PH_DECL
     M::barrier();                       // previous users of the arrays are done
@@ -1075,6 +1104,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
         }
         if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
+        const double rad_b = (MODE == PASS_BOUND && nk.ok) ? (double)__builtin_amdgcn_sqrtf((float)(bandt * nk.invK)) : 0.0;   // half-width of the bounding pass's candidate interval (metres)
         const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         if constexpr (MODE == PASS_EXACT) {
             u64 bb = ~0ull; int bn = 0x7fffffff;
@@ -1142,10 +1172,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
                     double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
                     double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
-                    double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
-                    double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
-                    double min_v = dmax_py(v + min_a * dt, 0.0);
-                    double max_v = dmin_py(v + max_a * dt, p.v_max);
+                    double min_a = dmax1(acc + p.j_min * dt, p.a_min);
+                    double max_a = dmin1(acc + p.j_max * dt, p.a_max);
+                    double min_v = dmax1(v + min_a * dt, 0.0);
+                    double max_v = dmin1(v + max_a * dt, p.v_max);
                     double min_s = sv + min_v * dt;
                     double max_s = sv + max_v * dt;
                     // st_cy.pyx:78-93
@@ -1164,26 +1194,23 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         // and absolute, against the rounding of the evaluated cost, which is below 1e-12 relative), so
                         // every candidate it drops has total cost > U; whatever it keeps is evaluated exactly as before.
                         if (nk.ok && ubits < INF_BITS && hi > lo) {
-                            const double slack = (__longlong_as_double((long long)ubits) - C) * (1.0 + 1e-9) + 1e-9;
-                            const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
-                            const double num = nk.kv * c_v + nk.ka * c_a + nk.kj * c_j;
-                            const double smin_ = num * nk.invK;
-                            const double emin = nk.kv * (c_v - smin_) * (c_v - smin_) + nk.ka * (c_a - smin_) * (c_a - smin_) +
-                                                nk.kj * (c_j - smin_) * (c_j - smin_);
+                            // (in the source's own frame: u = s_n - sv, see EdgeQuad; d1, d2 are the differences the range above already formed)
+                            double m_, emin, mag;
+                            edge_quad_source(nk, sv - p1, p1 - p2, m_, emin, &mag);
+                            // slack inflated by 1e-9 relative and absolute against the rounding of the evaluated cost, and by 1e-12 of the
+                            // magnitude emin is a difference of (its own rounding: a few 1e-16 of that)
+                            const double slack = __builtin_fma(__longlong_as_double((long long)ubits) - C, 1.0 + 1e-9, __builtin_fma(mag, 1e-12, 1e-9));
                             const double room = slack - emin;
                             if (!(room >= 0.0)) { if (hi > lo) cut_l = true; lo = 0; hi = 0; }
                             else {
-                                // single-precision square root, nudged up: 1e-6 relative of a radius of at most a few hundred cells
-                                // (3 instructions instead of the ~20 of the double-precision expansion)
-                                const double rad = (double)(__builtin_sqrtf((float)(room * nk.invK)) * 1.000001f);
-                                // cells outside [smin_ - rad, smin_ + rad] cost more than the inflated slack; 0.01 cell covers the rounding
-                                // of the lattice coordinates and of this interval (below 1e-3 cell with the radius above)
-                                const double fl = ceil((smin_ - rad - start_s) * r_delta - 0.01);
-                                const double fh = floor((smin_ + rad - start_s) * r_delta + 0.01) + 1.0;
-                                const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
-                                const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                                // radius from the hardware's single-precision square root (1 ulp), nudged up by 1e-5: an over-estimate of at most
+                                // 0.05 cell even for a radius of 5000 cells.  Cells outside [m - rad, m + rad] cost more than the inflated slack;
+                                // 0.01 cell covers the rounding of the lattice coordinates and of this interval.
+                                const double rad = (double)(__builtin_amdgcn_sqrtf((float)(room * nk.invK)) * 1.00001f);
+                                const int nlo_ = i + (int)ceil(__builtin_fma(m_ - rad, r_delta, -0.01));
+                                const int nhi_ = i + (int)floor(__builtin_fma(m_ + rad, r_delta, 0.01)) + 1;
                                 if (nlo_ > lo || nhi_ < hi) cut_l = true;
-                                lo = nlo_; hi = nhi_;
+                                lo = nlo_ > lo ? nlo_ : lo; hi = nhi_ < hi ? nhi_ : hi;
                             }
                         }
                     }
@@ -1192,22 +1219,19 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         // more than the band would fall outside the next layer's band anyway (the pre-pass may drop
                         // anything; it only has to find some complete path).
                         if (nk.ok && hi > lo) {
-                            const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
-                            const double smin_ = (nk.kv * c_v + nk.ka * c_a + nk.kj * c_j) * nk.invK;
                             // the three quadratic terms of st_cy.pyx:46-50 as ONE quadratic K (s_n - smin_)^2 + emin: what the candidate loop evaluates
-                            q_smin = smin_;
-                            q_base = Cf + (float)(nk.kv * (c_v - smin_) * (c_v - smin_) + nk.ka * (c_a - smin_) * (c_a - smin_) +
-                                                  nk.kj * (c_j - smin_) * (c_j - smin_));
+                            double m_, emin;
+                            edge_quad_source(nk, sv - p1, p1 - p2, m_, emin);
+                            q_smin = sv + m_;
+                            q_base = Cf + (float)emin;
                             // (no spare cells beyond the interval: the band is a heuristic)
-                            const double rad = (double)__builtin_sqrtf((float)(bandt * nk.invK));
-                            const double fl = ceil((smin_ - rad - start_s) * r_delta);
-                            const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
-                            const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
-                            const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
+                            const int nlo_ = i + (int)ceil((m_ - rad_b) * r_delta);
+                            const int nhi_ = i + (int)floor((m_ + rad_b) * r_delta) + 1;
                             // never drop everything: a source whose whole window lies off the minimiser keeps its nearest end
-                            if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
-                            else if (nlo_ >= hi) { lo = hi - 1; }
-                            else { hi = lo + 1; }
+                            const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
+                            if (a_ < b_) { lo = a_; hi = b_; }
+                            else if (nlo_ >= hi) lo = hi - 1;
+                            else hi = lo + 1;
                         } else { q_smin = sv; q_base = Cf; }      // (no quadratic part: the edge cost is the gap penalty alone)
                         if (tube_w > 0) { lo = lo > tube_lo ? lo : tube_lo; hi = hi < tube_hi ? hi : tube_hi; }      // targets outside the next layer's tube would not be selected anyway
                     }
@@ -1468,11 +1492,12 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
         if constexpr (S1GEN) { if (!s1_plain) { if (n == 1) v = ep.s1; } }
         return v;
     };
-    const double kv = p.v_w / p.dt2, ka = p.a_w / (p.dt2 * p.dt2), kj = p.j_w / (p.dt3 * p.dt3), K = kv + ka + kj, invK = 1.0 / K;
-    const bool quad = K > 0.0 && invK < 1e300;
+    const EdgeQuad nk = edge_quad(p);
+    const double K = nk.K, invK = nk.invK;
+    const bool quad = nk.ok;
     const float Kf = (float)K, stepf = (float)delta;
     const float bandf = (float)a.band;
-    const double rad = quad ? (double)__builtin_sqrtf((float)(a.band * invK)) : 0.0;       // (the band is constant here: a tube layer never exceeds band_cap nodes)
+    const double rad = quad ? (double)__builtin_amdgcn_sqrtf((float)(a.band * invK)) : 0.0;       // (the band is constant here: a tube layer never exceeds band_cap nodes)
     u64 *cur = cells, *nxt = cells + 256;
     M::barrier();                        // previous users of the arrays are done
     M::st64(&cur[tid], (tid == w) ? 0ull : INF_BITS);          // layer 0: cell 0 (the guide's cell of layer 0) at cost 0, no history
@@ -1541,10 +1566,10 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
                 const double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
                 const double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
                 const double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
-                const double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
-                const double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
-                const double min_v = dmax_py(v + min_a * dt, 0.0);
-                const double max_v = dmin_py(v + max_a * dt, p.v_max);
+                const double min_a = dmax1(acc + p.j_min * dt, p.a_min);
+                const double max_a = dmin1(acc + p.j_max * dt, p.a_max);
+                const double min_v = dmax1(v + min_a * dt, 0.0);
+                const double max_v = dmin1(v + max_a * dt, p.v_max);
                 const double min_s = sv + min_v * dt, max_s = sv + max_v * dt;
                 const double x = divc<FASTDIV>(min_s - start_s, delta, r_delta);
                 int mi = (int)x;
@@ -1554,17 +1579,16 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
                 if (hi > S) hi = S;
                 if (lo < i) lo = i;
                 if (quad && hi > lo) {
-                    const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
-                    const double smin_ = (kv * c_v + ka * c_a + kj * c_j) * invK;
-                    q_smin = smin_;
-                    q_base = Cf + (float)(kv * (c_v - smin_) * (c_v - smin_) + ka * (c_a - smin_) * (c_a - smin_) + kj * (c_j - smin_) * (c_j - smin_));
-                    const double fl = ceil((smin_ - rad - start_s) * r_delta);
-                    const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
-                    const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
-                    const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
-                    if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
-                    else if (nlo_ >= hi) { lo = hi - 1; }
-                    else { hi = lo + 1; }
+                    double m_, emin;
+                    edge_quad_source(nk, sv - p1, p1 - p2, m_, emin);
+                    q_smin = sv + m_;
+                    q_base = Cf + (float)emin;
+                    const int nlo_ = i + (int)ceil((m_ - rad) * r_delta);
+                    const int nhi_ = i + (int)floor((m_ + rad) * r_delta) + 1;
+                    const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
+                    if (a_ < b_) { lo = a_; hi = b_; }
+                    else if (nlo_ >= hi) lo = hi - 1;
+                    else hi = lo + 1;
                 } else { q_smin = sv; q_base = Cf; }
                 lo = lo > base1 ? lo : base1; hi = hi < base1 + TW ? hi : base1 + TW;      // the next layer's tube
                 if (lo >= hi) { lo = 0; hi = 0; }
@@ -1633,8 +1657,9 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
         if constexpr (S1GEN) { if (!s1_plain) { if (n == 1) v = ep.s1; } }
         return v;
     };
-    const double kv = p.v_w / p.dt2, ka = p.a_w / (p.dt2 * p.dt2), kj = p.j_w / (p.dt3 * p.dt3), K = kv + ka + kj, invK = 1.0 / K;
-    const bool quad = K > 0.0 && invK < 1e300;
+    const EdgeQuad nk = edge_quad(p);
+    const double K = nk.K, invK = nk.invK;
+    const bool quad = nk.ok;
     const float Kf = (float)K, stepf = (float)delta;
     const int mshift = a.maxshift - 62;          // every target lies below (its source) + mshift (SolveArgs::maxshift carries 66 cells of alignment slack)
     u64 *cur = (u64 *)lds, *nxt = cur + STMPC_BAND_W;
@@ -1676,7 +1701,7 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
         int thi = shi + mshift; thi = thi > S ? S : thi;
         if (thi - slo > STMPC_BAND_W) { rc = 2; break; }    // (workgroup-uniform)
         const int base1 = slo;
-        const double rad = (double)__builtin_sqrtf((float)(bandt * invK));
+        const double rad = (double)__builtin_amdgcn_sqrtf((float)(bandt * invK));
         // ---- next layer: "not reached" everywhere, penalties where a target can land
         {
             const size_t row = (size_t)e * H + (t + 1);
@@ -1741,10 +1766,10 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
                 const double prev_v = divk<FASTDIV>(p1 - p2, dt, r_dt, zl_dt);
                 const double v = divk<FASTDIV>(sv - p1, dt, r_dt, zl_dt);
                 const double acc = divk<FASTDIV>(v - prev_v, dt, r_dt, zl_dt);
-                const double min_a = dmax_py(acc + p.j_min * dt, p.a_min);
-                const double max_a = dmin_py(acc + p.j_max * dt, p.a_max);
-                const double min_v = dmax_py(v + min_a * dt, 0.0);
-                const double max_v = dmin_py(v + max_a * dt, p.v_max);
+                const double min_a = dmax1(acc + p.j_min * dt, p.a_min);
+                const double max_a = dmin1(acc + p.j_max * dt, p.a_max);
+                const double min_v = dmax1(v + min_a * dt, 0.0);
+                const double max_v = dmin1(v + max_a * dt, p.v_max);
                 const double min_s = sv + min_v * dt, max_s = sv + max_v * dt;
                 const double x = divc<FASTDIV>(min_s - start_s, delta, r_delta);
                 int mi = (int)x;
@@ -1754,17 +1779,16 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
                 if (hi > S) hi = S;
                 if (lo < i) lo = i;
                 if (quad && hi > lo) {
-                    const double c_v = sv + p.v_des * dt, c_a = 2.0 * sv - p1, c_j = 3.0 * sv - 3.0 * p1 + p2;
-                    const double smin_ = (kv * c_v + ka * c_a + kj * c_j) * invK;
-                    q_smin = smin_;
-                    q_base = Cf + (float)(kv * (c_v - smin_) * (c_v - smin_) + ka * (c_a - smin_) * (c_a - smin_) + kj * (c_j - smin_) * (c_j - smin_));
-                    const double fl = ceil((smin_ - rad - start_s) * r_delta);
-                    const double fh = floor((smin_ + rad - start_s) * r_delta) + 1.0;
-                    const int nlo_ = fl > (double)lo ? (fl < 2.0e9 ? (int)fl : hi) : lo;
-                    const int nhi_ = fh < (double)hi ? (fh > -2.0e9 ? (int)fh : lo) : hi;
-                    if (nlo_ < nhi_) { lo = nlo_; hi = nhi_; }
-                    else if (nlo_ >= hi) { lo = hi - 1; }
-                    else { hi = lo + 1; }
+                    double m_, emin;
+                    edge_quad_source(nk, sv - p1, p1 - p2, m_, emin);
+                    q_smin = sv + m_;
+                    q_base = Cf + (float)emin;
+                    const int nlo_ = i + (int)ceil((m_ - rad) * r_delta);
+                    const int nhi_ = i + (int)floor((m_ + rad) * r_delta) + 1;
+                    const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
+                    if (a_ < b_) { lo = a_; hi = b_; }
+                    else if (nlo_ >= hi) lo = hi - 1;
+                    else hi = lo + 1;
                 } else { q_smin = sv; q_base = Cf; }
                 if (hi > thi) hi = thi;              // (cannot happen: thi bounds every target; keeps the window safe)
                 if (lo >= hi) { lo = 0; hi = 0; }

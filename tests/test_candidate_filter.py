@@ -33,24 +33,38 @@ def _totals(q, start, i, pr, pp, C, n):
     return C[:, None] + ec
 
 
-def _interval(q, start, i, pr, pp, C, U):
-    """[nlo, nhi) of the kernel's filter (nhi <= nlo: everything dropped); the kernel then intersects it with the source's range."""
+def _interval(q, start, i, pr, pp, C, U, wobble=None):
+    """[nlo, nhi) of the kernel's filter (nhi <= nlo: everything dropped); the kernel then intersects it with the source's range.
+    The kernel works in the source's frame (EdgeQuad in stmpc_kernels.hpp): u = s_n - s, d1 = s - s_1, d2 = s_1 - s_2.  Its FMAs are
+    restated with separate roundings; `wobble` (a relative perturbation of m, emin and the radius, far above one rounding) shows that the
+    margins, not the last bits of these intermediates, are what the guarantee rests on."""
     dt = q["dt"]; dt2 = dt * dt; dt3 = dt2 * dt
     kv = q["v_w"] / dt2; ka = q["a_w"] / (dt2 * dt2); kj = q["j_w"] / (dt3 * dt3)
-    invK = 1.0 / (kv + ka + kj)
+    K = kv + ka + kj
+    invK = 1.0 / K
     r_delta = 1.0 / q["delta"]
+    A = q["v_des"] * dt
+    w0 = kv * A * invK; w1 = (ka + 2.0 * kj) * invK; w2 = -kj * invK; kvA2 = kv * A * A
     sv = _sval(start, q["delta"], i); p1 = _sval(start, q["delta"], pr); p2 = _sval(start, q["delta"], pp)
-    slack = (U - C) * (1.0 + 1e-9) + 1e-9
-    c_v = sv + q["v_des"] * dt; c_a = 2.0 * sv - p1; c_j = 3.0 * sv - 3.0 * p1 + p2
-    num = kv * c_v + ka * c_a + kj * c_j
-    smin = num * invK
-    emin = kv * (c_v - smin) * (c_v - smin) + ka * (c_a - smin) * (c_a - smin) + kj * (c_j - smin) * (c_j - smin)
+    d1 = sv - p1; d2 = p1 - p2
+    cj = 2.0 * d1 - d2
+    m = w1 * d1 + (w2 * d2 + w0)
+    t = (kj * cj) * cj + ((ka * d1) * d1 + kvA2)
+    km2 = K * m * m
+    emin = t - km2
+    mag = t + km2
+    if wobble is not None:
+        m = m * (1.0 + wobble[0]); emin = emin + mag * wobble[1]
+    slack = (U - C) * (1.0 + 1e-9) + (mag * 1e-12 + 1e-9)
     room = slack - emin
     ok = room >= 0.0
-    rad = (np.sqrt((np.where(ok, room, 0.0) * invK).astype(np.float32)) * np.float32(1.000001)).astype(np.float64)      # as the kernel: float sqrt, nudged up
-    fl = np.ceil((smin - rad - start) * r_delta - 0.01)
-    fh = np.floor((smin + rad - start) * r_delta + 0.01) + 1.0
-    nlo = np.where(ok, fl, 0.0).astype(np.int64); nhi = np.where(ok, fh, 0.0).astype(np.int64)
+    rad = (np.sqrt((np.where(ok, room, 0.0) * invK).astype(np.float32)) * np.float32(1.00001)).astype(np.float64)      # as the kernel: float sqrt (1 ulp), nudged up
+    if wobble is not None:
+        rad = rad * (1.0 - 2e-7)                                          # the hardware's v_sqrt_f32 may be an ulp below the correctly rounded root
+    fl = np.ceil((m - rad) * r_delta - 0.01)
+    fh = np.floor((m + rad) * r_delta + 0.01) + 1.0
+    nlo = i + np.where(ok, fl, 0.0).astype(np.int64); nhi = i + np.where(ok, fh, 0.0).astype(np.int64)
+    nlo = np.where(ok, nlo, 0); nhi = np.where(ok, nhi, 0)
     return nlo, nhi
 
 
@@ -84,6 +98,9 @@ def test_filter_never_drops_a_candidate_within_the_bound(name):
     kept = (n >= nlo[:, None]) & (n < nhi[:, None])
     bad = within & ~kept
     assert not bad.any(), "dropped a candidate with total <= bound: trial %d" % int(np.argwhere(bad)[0][0])
+    for sign in (1.0, -1.0):                                             # intermediates off by 1e-13 relative (hundreds of roundings) either way
+        wl, wh = _interval(q, start, i, pr, pp, C, U, wobble=(sign * 1e-13, sign * 1e-13))
+        assert not (within & ~((n >= wl[:, None]) & (n < wh[:, None]))).any()
     # and it is a filter worth having: away from the equality cases it keeps at most one cell beyond the true interval on either side
     true_n = within.sum(1); kept_n = kept.sum(1)
     sel = (kinds == 0) & (true_n > 0)

@@ -1,8 +1,12 @@
 """batched SUMO-free merge episodes.  STATISTICAL parity, and labelled so: the world restates the SUMO scenario the
 reference configures (Krauss vehicles of its "simple traffic distribution", the ego under speed mode 22) but is not SUMO.  The test
 compares the per-episode means of the reference's pure-ST evaluation at its three traffic densities (experiment_data/saved_data.csv,
-rows st_low / st_medium / st_default, 4000-10000 SUMO episodes each) with 1024 episodes of this world: every episode merges, none
-crashes, time to merge within 15 %, mean speed within 10 % -- measured: within 2.5 % and 3 %."""
+rows st_low / st_medium / st_default, 4000-10000 SUMO episodes each) with 1024 episodes of this world, with tolerances set just above
+what is measured (time to merge +0.9 ... +2.4 %, mean speed -1.4 ... -2.9 %, mean |jerk| -1 ... -2 % in dense and
+medium traffic): every episode merges, at most 0.5 % crash (reference: none), time to merge and mean speed within 5 %, maximum speed
+within 3 %, closest distance within 6 %, mean |jerk| within 10 % at 1.8 s and 1.2 s headway.  Known gap, kept visible instead of hidden
+in a loose bound: mean |jerk| at 2.4 s headway is +20 % (1.29 against 1.07) and is asserted to lie in that band -- a move in either
+direction fails the test and has to be looked at."""
 import numpy as np
 import pytest
 
@@ -24,18 +28,21 @@ def test_st_episodes_match_the_reference_statistically(interval, gpu_ctx, restor
     s = episodes.summary(st)
     ref = REFERENCE_ST[interval]
     assert (st["crashed"] + st["merged"] + st["timed_out"] == 1).all()
-    assert s["merged"] >= 0.97                                    # reference: 1.0
-    assert s["crashed"] <= 0.01                                   # reference: 0.0
-    assert abs(s["time_to_merge"] - ref["time_to_merge"]) <= 0.15 * ref["time_to_merge"]
-    assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.10 * ref["mean_speed"]
-    assert abs(s["max_speed"] - ref["max_speed"]) <= 0.05 * ref["max_speed"]
-    assert abs(s["mean_abs_jerk"] - ref["mean_abs_jerk"]) <= 0.30 * ref["mean_abs_jerk"]        # (measured: +20 % in light traffic, +-2 % in dense)
-    assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.10 * ref["closest_distance"]
+    assert s["merged"] >= 0.995                                   # reference: 1.0
+    assert s["crashed"] <= 0.005                                  # reference: 0.0 (measured 0 / 0.0005 / 0.0015)
+    assert abs(s["time_to_merge"] - ref["time_to_merge"]) <= 0.05 * ref["time_to_merge"]
+    assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.05 * ref["mean_speed"]
+    assert abs(s["max_speed"] - ref["max_speed"]) <= 0.03 * ref["max_speed"]
+    jerk_dev = s["mean_abs_jerk"] / ref["mean_abs_jerk"] - 1.0
+    if interval == 2.4:
+        assert 0.10 <= jerk_dev <= 0.30, jerk_dev                  # the known gap in light traffic (+20 %): neither worse nor silently "fixed"
+    else:
+        assert abs(jerk_dev) <= 0.10, jerk_dev
+    assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.06 * ref["closest_distance"]
     if interval == 2.4:
         # determinism: same seed, same episodes
-        st2 = episodes.run_episodes(256, seed=7, controller="st", ctx=gpu_ctx)
-        st3 = episodes.run_episodes(256, seed=7, controller="st", ctx=gpu_ctx)
-        assert np.array_equal(st3["ticks"], st2["ticks"]) and np.array_equal(st3["mean_speed"], st2["mean_speed"])
+        st2 = episodes.run_episodes(n, seed=7, controller="st", ctx=gpu_ctx)
+        assert np.array_equal(st["ticks"], st2["ticks"]) and np.array_equal(st["mean_speed"], st2["mean_speed"])
 
 
 @pytest.mark.gpu
