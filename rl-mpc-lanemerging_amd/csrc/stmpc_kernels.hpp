@@ -776,7 +776,7 @@ struct PassOut {
 #define STMPC_MAXWAVES 8
 struct WgShared {
     int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
-    int agg[8];                           // the same over the whole workgroup (LDS atomics; reset after every round that used them); the
+    int agg[8];                           // (-min lo, max hi, max fan, -lowest source) over the whole workgroup (one LDS atomic per wave; reset after every round that used them); the
                                           // bounding pass alternates between two sets (its rounds have no barrier after the candidates)
     u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
     int best_n[STMPC_MAXWAVES];
@@ -794,10 +794,10 @@ enum { PASS_EXACT = 0, PASS_BOUND = 1 };
 // Reset of a set of workgroup-wide round figures (min lo, max hi, max fan).  The constants are made opaque where they are used: left to itself
 // the compiler materialises the triple once per kernel, runs out of registers, and reloads it from SCRATCH in front of every reset -- a global
 // memory round trip for the one wave every other wave then waits for at the next barrier.
-__device__ __forceinline__ void agg_reset(int *g) {
-    int big = 0x7fffffff, zero = 0;
-    asm volatile("" : "+v"(big), "+v"(zero));
-    g[0] = big; g[1] = zero; g[2] = zero;
+__device__ __forceinline__ void agg_reset(int *g) {      // (-min lo, max hi, max fan, -min source): all folded with ds_max_i32
+    int nbig = -0x7fffffff, zero = 0;
+    asm volatile("" : "+v"(nbig), "+v"(zero));
+    g[0] = nbig; g[1] = zero; g[2] = zero; g[3] = nbig;
 }
 
 // One forward sweep over the layers by one WORKGROUP of NW wavefronts.  Returns 0 ok, 1 window overflow
@@ -1244,19 +1244,25 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (relax) {
                 const int clo_w = wave_min_i(hi > lo ? lo : 0x7fffffff), chi_w = wave_max_i(hi);
                 const int fan_w = wave_max_i(hi - lo);
-                if (lane == 0) {
-                    sh.red[wave * 4 + 0] = clo_w; sh.red[wave * 4 + 1] = chi_w; sh.red[wave * 4 + 2] = fan_w;
-                    atomicMin(&sh.agg[ab + 0], clo_w); atomicMax(&sh.agg[ab + 1], chi_w); atomicMax(&sh.agg[ab + 2], fan_w);
+                // lowest source of the wave's share of the round: the list is descending, so it is the last listed lane's
+                const u64 im = __ballot(inlist);
+                const int low_w = im != 0ull ? __builtin_amdgcn_readlane(i, 63 - __builtin_clzll(im)) : 0x7fffffff;
+                // four lanes, one LDS write and one LDS atomic: the wave's figures, and their fold into the workgroup-wide ones -- all as
+                // maxima (the two minima negated), so that a single ds_max_i32 with four addresses does it
+                if (lane < 4) {
+                    const int raw = lane == 0 ? clo_w : (lane == 1 ? chi_w : (lane == 2 ? fan_w : low_w));
+                    sh.red[wave * 4 + lane] = raw;
+                    atomicMax(&sh.agg[ab + lane], (lane == 0 || lane == 3) ? -raw : raw);
                 }
             }
             STMPC_BARW(1);    // B1: the round's sources are in registers: their cells may now be overwritten
             STMPC_PH(5);                // 5: wave reductions + B1
             // The round takes the leading kw waves' sources: as many as keep the targets within the penalty buffer -- nearly always all
             // of them, which the workgroup-wide figures show at once; the per-wave walk is the rare fallback.
-            int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0;
+            int kw = NW, clo = 0x7fffffff, chi = 0, fan = 0, low_all = 0;
             bool agg_used = false;
             if (relax) {
-                clo = sh.agg[ab + 0]; chi = sh.agg[ab + 1]; fan = sh.agg[ab + 2];
+                clo = -sh.agg[ab + 0]; chi = sh.agg[ab + 1]; fan = sh.agg[ab + 2]; low_all = -sh.agg[ab + 3];
                 agg_used = chi > clo;           // (untouched initial values otherwise: nothing to reset)
                 if (chi > clo && (((chi + 63) & ~63) - (clo & ~63)) > PW) {
                     kw = 0; clo = 0x7fffffff; chi = 0; fan = 0;
@@ -1278,8 +1284,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
             if (!act) { lo = 0; hi = 0; }
             if (!relax) continue;
-            const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1;
-            const int a_k = list_at(rlast);                      // lowest source of this round (uniform)
+            // lowest source of this round (uniform): the workgroup-wide figure when every wave's sources are taken, a list lookup otherwise
+            int a_k = low_all;
+            if (kw != NW) { const int rlast = (r0 + rstep < nlist ? r0 + rstep : nlist) - 1; a_k = list_at(rlast); }
             if (clo >= chi) {                                 // (keeps sh.red / sh.agg stable until everyone has read them)
                 M::barrier();
                 if (agg_used) { if (tid == 0) agg_reset(&sh.agg[ab]); M::barrier(); }     // (fallback walk that took an empty wave only)
