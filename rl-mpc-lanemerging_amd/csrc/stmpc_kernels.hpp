@@ -286,6 +286,13 @@ struct CarTab {
 //                blocked index window, the break / continue rules as ballots over the layer's lanes, entries compacted in vehicle order, one table
 //                row per lane group (coalesced) -- and the guide's cell of the layer checked against each listed vehicle.
 // (Round 3 ran all of it as one thread per episode: 119 us of serial prefix per step of 4096 episodes.)
+// The vehicle table is written by k_predict and only read by the solve kernels: its rows are wave-uniform data, fetched through the scalar
+// cache (s_load) by reading them in the constant address space -- no vector-memory instruction, no per-lane address arithmetic.
+typedef const double __attribute__((address_space(4))) stmpc_cdouble;
+typedef const int __attribute__((address_space(4))) stmpc_cint;
+__device__ __forceinline__ stmpc_cdouble *as_const(const double *q) { return (stmpc_cdouble *)(unsigned long long)q; }
+__device__ __forceinline__ stmpc_cint *as_const(const int *q) { return (stmpc_cint *)(unsigned long long)q; }
+
 template <int KMAX> struct PredShape { static constexpr int E = 32 / KMAX; };
 
 // lane i <- lane i-1 within an aligned group of GL lanes (the group's first lane gets something it never uses): a DPP row shift where
@@ -885,7 +892,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     const int per = NW * 64;
     const int W = SH::fixed ? SH::W : a.W, WM = W - 1;
     const int PW = SH::fixed ? SH::PW : a.PW, PWM = PW - 1;
-    const int H = p.H, S = ep.S, e = ep.e;
+    const int H = p.H, S = ep.S, e = __builtin_amdgcn_readfirstlane(ep.e);      // (uniform by construction; said so that the vehicle rows are fetched by scalar loads)
     const double start_s = ep.start_s, delta = ep.delta, s1 = ep.s1;
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
     const double r_dt = ep.r_dt, r_dt2 = ep.r_dt2, r_dt3 = ep.r_dt3, r_delta = ep.r_delta;
@@ -945,8 +952,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         int nact = 0;
         double cfront[KT > 0 ? KT : 1], cback[KT > 0 ? KT : 1];
         int cimin[KT > 0 ? KT : 1], cimax[KT > 0 ? KT : 1];
-        const double *cedge = nullptr;
-        const int *cwin = nullptr;
+        stmpc_cdouble *cedge = nullptr;
+        stmpc_cint *cwin = nullptr;
         if constexpr (!GRID) {
             if (relax) {
                 size_t row = (size_t)e * H + (t + 1);
@@ -968,9 +975,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         cimax[c] = __builtin_amdgcn_readlane(i1, c);
                     }
                 } else {
-                    nact = a.tab.nact[row];
-                    cedge = a.tab.edge + row * a.Kmax * 2;
-                    cwin = a.tab.win + row * a.Kmax * 2;
+                    nact = as_const(a.tab.nact)[row];
+                    cedge = as_const(a.tab.edge) + row * a.Kmax * 2;
+                    cwin = as_const(a.tab.win) + row * a.Kmax * 2;
                 }
             }
         }
@@ -1490,7 +1497,7 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
     typedef Mem<true> M;
     const DevP &p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = p.H, S = ep.S, e = ep.e, w = a.tube_w, TW = 2 * w + 1;
+    const int H = p.H, S = ep.S, e = __builtin_amdgcn_readfirstlane(ep.e), w = a.tube_w, TW = 2 * w + 1;
     const double start_s = ep.start_s, delta = ep.delta, dt = p.dt;
     const double r_dt = ep.r_dt, r_delta = ep.r_delta, zl_dt = a.zl_dt;
     const bool s1_plain = ep.s1_plain;
@@ -1520,9 +1527,9 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
             float pf = -1.0f;
             if (tid < TW && n1 >= 0 && n1 < S) {
                 const size_t row = (size_t)e * H + (t + 1);
-                int nact = a.tab.nact[row];
-                const double *cedge = a.tab.edge + row * a.Kmax * 2;
-                const int *cwin = a.tab.win + row * a.Kmax * 2;
+                int nact = as_const(a.tab.nact)[row];
+                stmpc_cdouble *cedge = as_const(a.tab.edge) + row * a.Kmax * 2;
+                stmpc_cint *cwin = as_const(a.tab.win) + row * a.Kmax * 2;
                 const double sn = sval(n1);
                 double d = 1e10;
                 bool blocked = false;
@@ -1655,7 +1662,7 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
     typedef Mem<true> M;
     const DevP &p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = p.H, S = ep.S, e = ep.e;
+    const int H = p.H, S = ep.S, e = __builtin_amdgcn_readfirstlane(ep.e);      // (uniform by construction; said so that the vehicle rows are fetched by scalar loads)
     const double start_s = ep.start_s, delta = ep.delta, dt = p.dt;
     const double r_dt = ep.r_dt, r_delta = ep.r_delta, zl_dt = a.zl_dt;
     const bool s1_plain = ep.s1_plain;
@@ -1712,9 +1719,9 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
         // ---- next layer: "not reached" everywhere, penalties where a target can land
         {
             const size_t row = (size_t)e * H + (t + 1);
-            const int nact = a.tab.nact[row];
-            const double *cedge = a.tab.edge + row * a.Kmax * 2;
-            const int *cwin = a.tab.win + row * a.Kmax * 2;
+            const int nact = as_const(a.tab.nact)[row];
+            stmpc_cdouble *cedge = as_const(a.tab.edge) + row * a.Kmax * 2;
+            stmpc_cint *cwin = as_const(a.tab.win) + row * a.Kmax * 2;
 #pragma unroll 1
             for (int s_ = 0; s_ < STMPC_BAND_SLOTS; ++s_) {
                 const int j = s_ * 256 + tid, n1 = base1 + j;
