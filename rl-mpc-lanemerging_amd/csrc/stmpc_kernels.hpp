@@ -143,7 +143,23 @@ __device__ __forceinline__ int wave_reduce_i(int v) {
 }
 __device__ __forceinline__ int wave_min_i(int v) { return wave_reduce_i<true>(v); }
 __device__ __forceinline__ int wave_max_i(int v) { return wave_reduce_i<false>(v); }
-// lexicographic min of (bits, n) across the wave
+// Wave-wide minimum of a 64-bit key on the DPP network (same steps as wave_reduce_i: no LDS crossbar round trips -- six dependent
+// ds_bpermute pairs cost ~900 cycles of a layer's critical path, these thirty VALU instructions ~150)
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#define STMPC_DPP_STEP64(CTRL, RMASK)                                                                           \
+    { const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)v, CTRL, RMASK, 0xf, false);   \
+      const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(v >> 32), CTRL, RMASK, 0xf, false); \
+      const u64 t_ = ((u64)hi_ << 32) | lo_; v = t_ < v ? t_ : v; }
+    STMPC_DPP_STEP64(0x111, 0xf)   // row_shr:1
+    STMPC_DPP_STEP64(0x112, 0xf)   // row_shr:2
+    STMPC_DPP_STEP64(0x114, 0xf)   // row_shr:4
+    STMPC_DPP_STEP64(0x118, 0xf)   // row_shr:8
+    STMPC_DPP_STEP64(0x142, 0xa)   // row_bcast:15 -> rows 1,3
+    STMPC_DPP_STEP64(0x143, 0xc)   // row_bcast:31 -> rows 2,3
+#undef STMPC_DPP_STEP64
+    return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+}
+// lexicographic min of (bits, n) across the wave (shuffles; kept for reference -- the passes use wave_min_u64 + wave_min_i)
 __device__ __forceinline__ void wave_min_key(u64 &bits, int &n) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1077,7 +1093,11 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 wn += __popcll(amask);
             }
             if (__ballot(pruned_l) && lane == 0) atomicOr(&sh.flags, 1);
-            if constexpr (MODE == PASS_EXACT) wave_min_key(my_best, my_best_n);
+            if constexpr (MODE == PASS_EXACT) {      // the wave's cheapest selected node, smallest cell among equals
+                const u64 wb = wave_min_u64(my_best);
+                const int wbn = wave_min_i(my_best == wb ? my_best_n : 0x7fffffff);
+                my_best = wb; my_best_n = wbn;
+            }
             if (lane == 0) {
                 sh.cnt[wave] = wn;
                 if constexpr (MODE == PASS_EXACT) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
@@ -1457,8 +1477,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         // ---- end of layer.  PASS_EXACT needs no barrier here: the next scan only reads cost[] (final since the
         // last round's B3) and its own S1 orders everything else.  PASS_BOUND publishes the cheapest candidate.
         if constexpr (MODE == PASS_BOUND) {
-            int dummy = 0;
-            wave_min_key(my_min_tot, dummy);
+            my_min_tot = wave_min_u64(my_min_tot);
             if (lane == 0) sh.min_tot[wave] = my_min_tot;
             STMPC_BARW(5);   // S2
             u64 mt = ~0ull;
@@ -1627,8 +1646,7 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
                 dcur += 4.0f * stepf;
             }
         }
-        int dummy = 0;
-        wave_min_key(my_min, dummy);
+        my_min = wave_min_u64(my_min);
         if (lane == 0) sh.min_tot[wave] = my_min;
         M::barrier();                    // B: every offer of this layer is in
         u64 mt = sh.min_tot[0];
@@ -1827,8 +1845,7 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
                 dcur += 4.0f * stepf;
             }
         }
-        int dummy = 0;
-        wave_min_key(my_min, dummy);
+        my_min = wave_min_u64(my_min);
         if (lane == 0) sh.min_tot[wave] = my_min;
         M::barrier();                    // B: every offer of this layer is in
         u64 mt = sh.min_tot[0];
