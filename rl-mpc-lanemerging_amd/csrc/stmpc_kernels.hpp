@@ -801,8 +801,8 @@ struct WgShared {
     int red[STMPC_MAXWAVES * 4];          // per-wave (min lo, max hi, max fan) of a round
     int agg[8];                           // (-min lo, max hi, max fan, -lowest source) over the whole workgroup (one LDS atomic per wave; reset after every round that used them); the
                                           // bounding pass alternates between two sets (its rounds have no barrier after the candidates)
-    u64 best_bits[STMPC_MAXWAVES];        // per-wave cheapest node of the layer
-    int best_n[STMPC_MAXWAVES];
+    u64 best_bits[2][STMPC_MAXWAVES];     // per-wave cheapest node of the layer, by layer parity: the waves' entries are only combined when a pass
+    int best_n[2][STMPC_MAXWAVES];        // ends (the deepest non-empty layer's set is then still in place), not once per layer
     u64 min_tot[STMPC_MAXWAVES];          // per-wave cheapest relaxed candidate (PASS_BOUND)
     int cnt[STMPC_MAXWAVES];              // per-wave number of selected cells of the layer
     int flags;                            // bit 0: a reached node was not expanded
@@ -940,6 +940,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     double bandt = band;           // PASS_BOUND: the band in force, steered towards a.band_cap expanded nodes per layer
     int total_nodes = 0;
     int maxspan = 0;
+    int last_t = -1;               // PASS_EXACT: deepest layer that had nodes to expand
 
     const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
     STMPC_PH(0);                        // 0: pass set-up
@@ -1100,7 +1101,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             }
             if (lane == 0) {
                 sh.cnt[wave] = wn;
-                if constexpr (MODE == PASS_EXACT) { sh.best_bits[wave] = my_best; sh.best_n[wave] = my_best_n; }
+                if constexpr (MODE == PASS_EXACT) { sh.best_bits[t & 1][wave] = my_best; sh.best_n[t & 1][wave] = my_best_n; }
             }
         }
         STMPC_BARW(0);       // S1
@@ -1134,18 +1135,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         const double rad_b = (MODE == PASS_BOUND && nk.ok) ? (double)__builtin_amdgcn_sqrtf((float)(bandt * nk.invK)) : 0.0;   // half-width of the bounding pass's candidate interval (metres)
         const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         if constexpr (MODE == PASS_EXACT) {
-            u64 bb = ~0ull; int bn = 0x7fffffff;
-            for (int w = 0; w < NW; ++w) {
-                const u64 b_ = sh.best_bits[w]; const int n_ = sh.best_n[w];
-                if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
-            }
-            out.best_t = t; out.best_n = bn; out.best_bits = bb;
+            last_t = t;                     // deepest non-empty layer so far (its cheapest node is looked up after the loop)
             if (RES == 1 && relax && t > 0) {
                 // will layer t+1 fit?  Every target lies within maxshift cells above its source, so the live span of
                 // the layer about to be built is at most (highest source + maxshift) - lowest source.
                 const int top_src = list_at(0), low_src = smin;
                 if (top_src + a.maxshift - low_src > W) {
                     ckpt_save<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
+                    out.best_t = t;             // the layer that was saved
                     out.nodes = nlist;          // (nodes of the layer that was saved: what is left to do scales with it, see solve_episode)
                     return 2;
                 }
@@ -1290,7 +1287,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             bool agg_used = false;
             if (relax) {
                 clo = -sh.agg[ab + 0]; chi = sh.agg[ab + 1]; fan = sh.agg[ab + 2]; low_all = -sh.agg[ab + 3];
-                agg_used = chi > clo;           // (untouched initial values otherwise: nothing to reset)
+                agg_used = chi > clo || low_all != 0x7fffffff;      // (untouched initial values otherwise: nothing to reset; a round whose sources have
+                                                                    // no candidate at all still folded its lowest source in)
                 if (chi > clo && (((chi + 63) & ~63) - (clo & ~63)) > PW) {
                     kw = 0; clo = 0x7fffffff; chi = 0; fan = 0;
                     for (int w = 0; w < NW; ++w) {
@@ -1491,6 +1489,17 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     }
     M::barrier();
     STMPC_PH_FLUSH(MODE);
+    if constexpr (MODE == PASS_EXACT) {
+        // the terminal of the search (st_cy.pyx:365-369): cheapest node of the deepest non-empty layer, smallest cell among equals
+        if (last_t >= 0) {
+            u64 bb = ~0ull; int bn = 0x7fffffff;
+            for (int w = 0; w < NW; ++w) {
+                const u64 b_ = sh.best_bits[last_t & 1][w]; const int n_ = sh.best_n[last_t & 1][w];
+                if (b_ < bb || (b_ == bb && n_ < bn)) { bb = b_; bn = n_; }
+            }
+            out.best_t = last_t; out.best_n = bn; out.best_bits = bb;
+        }
+    }
     if constexpr (MODE == PASS_BOUND) {
         // the bound: the path's cost as accumulated in single precision (error below 1e-5 relative: <= 2^-23 per operation, ~4 operations
         // per layer, H layers), inflated beyond that -- any value is safe, the exact pass re-checks
