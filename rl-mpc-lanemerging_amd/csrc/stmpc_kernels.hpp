@@ -159,16 +159,6 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 #undef STMPC_DPP_STEP64
     return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
 }
-// lexicographic min of (bits, n) across the wave (shuffles; kept for reference -- the passes use wave_min_u64 + wave_min_i)
-__device__ __forceinline__ void wave_min_key(u64 &bits, int &n) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        u64 ob = __shfl_xor(bits, o);
-        int on = __shfl_xor(n, o);
-        if (ob < bits || (ob == bits && on < n)) { bits = ob; n = on; }
-    }
-}
-
 // control.py:373-380 get_ego_s with x*x for the squares (host code uses libm pow exactly like
 // the reference; on the device this only feeds the >8 / >11 threshold tests, prediction.py:64-66).
 __device__ __forceinline__ double dev_ego_s(double x, double y) {
