@@ -423,7 +423,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         out["parity_vs_oracle"] = {"episodes": mp, **parity}
         # fp64 work: (1) what the reference's algorithm does (heap Dijkstra: settled nodes, relaxed edges, counted by the oracle on
         # the same states), (2) what the full layered DP would do, (3) what the kernel executed (node counters of this run; candidate
-        # evaluations per node from the analysis build's counters in profiles/r3/measured.json)
+        # evaluations per node from the analysis build's counters in the newest profiles/rN/measured.json, flagged stale when taken from other sources)
         hp, ly = counts["heap"], counts["layered"]
         mh = hp["path_idx"].shape[0]
         ref_flops = (27 * hp["edges"] + 26 * hp["nodes"]) / mh + 40 * K * H
