@@ -155,3 +155,19 @@ def test_synth_generator_is_seeded_and_ordered():
     ego, k, ox, ov = a
     assert (np.diff(ox[:, :6], axis=1) < 0).all()            # front -> back
     assert (ego[:, 2] - ego[:, 3] * 0.3 >= -1e-12).all()
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """The built library names the sources it was compiled from (build.source_hash -> -DSTMPC_SRC_HASH -> stmpc_backend_info); bench.py uses
+    that to mark counters taken from another build as stale, and the committed counters of the newest round belong to these sources."""
+    import json, os
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi
+    from conftest import REPO
+    import pytest
+    h = pkg.build.source_hash()
+    if pkg.build.needs_build():
+        pytest.skip("libstmpc.so is older than its sources (run __graft_entry__.build())")
+    assert len(h) == 16 and _capi.library_source_hash() == h, "libstmpc.so was built from other sources: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+    measured = json.load(open(os.path.join(REPO, "profiles", "r4", "measured.json")))
+    assert all("csrc_hash" in v for v in measured.values())
