@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef unsigned long long u64;
 typedef unsigned short u16;
@@ -1377,6 +1378,17 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             } else {
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
             for (int cbase = 0; (cbase << gsh) < fan; cbase += FANMAX) {
+                // A batch whose candidate cells do not wrap around the circular arrays (and whose lanes own one source each) addresses them as
+                // one base per array plus the slot number -- immediate offsets of the LDS instructions -- instead of (cell & mask) * size per
+                // access: eight address instructions less per slot.  Chosen per wave and batch; both forms execute the same barriers.
+                const int c0 = cand(cbase);
+                const bool fastb = USE_LDS && gsh == 0 && __ballot(((c0 & WM) + FANMAX > W) | ((c0 & PWM) + FANMAX > PW)) == 0ull;
+                auto batch = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                u64 *const cbp = &cost[c0 & WM]; double *const pbp = &pen[c0 & PWM]; unsigned *const hbp = &hist[c0 & WM];
+                auto cost_at = [&](int j) -> u64 * { if constexpr (FAST) return cbp + j; else return &cost[cand(cbase + j) & WM]; };
+                auto pen_at = [&](int j) -> double * { if constexpr (FAST) return pbp + j; else return &pen[cand(cbase + j) & PWM]; };
+                auto hist_at = [&](int j) -> unsigned * { if constexpr (FAST) return hbp + j; else return &hist[cand(cbase + j) & WM]; };
                 u64 tb[FANMAX];
                 unsigned improved = 0u, tied = 0u;
                 STMPC_PH_COUNT(13);
@@ -1393,10 +1405,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         // then offer ~0, which a min never takes
                         double pn[UB];
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) pn[u] = M::ldf(&pen[cand(cbase + ub + u) & PWM]);
+                        for (int u = 0; u < UB; ++u) pn[u] = M::ldf(pen_at(ub + u));
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            const int n = cand(cbase + ub + u);
+                            const int n = FAST ? c0 + (ub + u) : cand(cbase + ub + u);
                             const double sn = sval(n);
                             // st_cy.pyx:46-50 cost_with_jerk(next, s, p1, p2)
                             const double v = divk<FASTDIV>(sn - sv, dt, r_dt, zl_dt);
@@ -1418,7 +1430,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            const u64 old = M::min64(&cost[cand(cbase + ub + u) & WM], tb[ub + u]);
+                            const u64 old = M::min64(cost_at(ub + u), tb[ub + u]);
                             if (old > tb[ub + u]) improved |= 1u << (ub + u);
                             else if (old == tb[ub + u]) tied |= 1u << (ub + u);
                         }
@@ -1436,10 +1448,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                     if (__ballot(((improved >> ub) & 0xFu) != 0u)) {
                         u64 cur[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(&cost[cand(cbase + ub + u) & WM]);
+                        for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(cost_at(ub + u));
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(&hist[cand(cbase + ub + u) & WM], key); }
+                            if (ub + u < FANMAX) { if (((improved >> (ub + u)) & 1u) && cur[u] == tb[ub + u]) M::st32(hist_at(ub + u), key); }
                     }
                 }
                 STMPC_BARW(4);    // B4
@@ -1450,13 +1462,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
 #pragma unroll
                         for (int u = 0; u < FANMAX; ++u) {
                             if ((tied >> u) & 1u) {
-                                const int sl = cand(cbase + u) & WM;
-                                if (M::ld64(&cost[sl]) == tb[u]) M::min32(&hist[sl], key);
+                                if (M::ld64(cost_at(u)) == tb[u]) M::min32(hist_at(u), key);
                             }
                         }
                     }
                 }
                 STMPC_PH(10);           // 10: stage C (tie repair)
+                };
+                if (fastb) batch(std::true_type{}); else batch(std::false_type{});
             }
             }
             if (last_round) break;
