@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["h40a21", "default", "control", "combined", "episodes"], default="h40a21",
                     help="h40a21: BASELINE workload; default: the reference's own lattice; control: st.do_st_control on the "
                          "reference's lattice (lattice search + QP re-sampling + commanded speed); combined: one tick of the "
-                         "RL+MPC combined controller (configs/combined_medium_1.json) with a stand-in policy network; episodes: batched merge "
+                         "RL+MPC combined controller (configs/combined_medium_1.json) with the reference's pretrained ddpg_medium1 actor; episodes: batched merge "
                          "environments with configs/train_moderate_1.json's traffic under that controller (BASELINE configs[4] as a labelled "
                          "throughput demo: the reference has no counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -16,6 +16,7 @@
  *   stmpc_st_control_batch[_device] <- st.do_st_control              st.py:757-783 applied to N independent states
  *   stmpc_rollout_step_device / stmpc_combined_decide_device <- dqn.RLAgent.do_combined_control  dqn.py:117-200 (the policy
  *                                network stays the caller's; everything around it runs here)
+ *   stmpc_policy_features_device <- dqn.get_state_vector_from_base_state  dqn.py:389-446 (+ the float32 cast and TimeFeature input of ddpg.py:41,84)
  *   stmpc_ego_s               <- control.get_ego_s                   control.py:373-380
  *   stmpc_num_s / stmpc_num_t <- the np.arange sizes at st.py:31-32
  *
@@ -68,7 +69,7 @@
 extern "C" {
 #endif
 
-#define STMPC_ABI_VERSION 3   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
+#define STMPC_ABI_VERSION 4   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
 
 #define STMPC_OK        0
 #define STMPC_EINVAL   -1   /* bad argument (NULL, size, Kmax/H/S out of range) */
@@ -306,6 +307,10 @@ typedef struct stmpc_combined_cfg {
     int32_t test_rollout_state;      /* Settings.TEST_ROLLOUT_STATE */
     int32_t test_st_strictly_better; /* Settings.TEST_ST_STRICTLY_BETTER */
     int32_t remember_last_choice;    /* Settings.REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED */
+    int32_t sparse_control;          /* not a reference flag.  1: like the reference, st.do_st_control(start_state) is solved only for the states whose decision hands
+                                        control over (dqn.py:144-155) -- the decide call then makes ONE host round trip (the number of those states) and is no longer
+                                        capturable in a hipGraph; ignored (all states are solved) when test_st_strictly_better needs every state's path.  0: all states,
+                                        fully asynchronous.  Same decisions and commands either way. */
 } stmpc_combined_cfg;
 int stmpc_rollout_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_combined_cfg *cfg, int N, int Kmax, int step,
                               const double *d_ego5_start, double *d_cur_ego4, const int32_t *d_k_count, double *d_cur_other_x,
@@ -315,9 +320,39 @@ int stmpc_combined_decide_device(stmpc_ctx *ctx, const stmpc_params *p, const st
                                  const double *d_other_v_start, const double *d_cur_ego4, const double *d_cur_other_x,
                                  const double *d_cur_other_v, const double *d_first_action, const int32_t *d_last_choice_rl,
                                  int32_t *d_takeover, int32_t *d_reason, double *d_speed, void *stream);
+/* Decisions taken by stmpc_combined_decide_device on this context and controller solves run for them (equal unless sparse_control). */
+int stmpc_combined_counts(stmpc_ctx *ctx, int64_t *decisions, int64_t *control_solves, int reset);
+
+/*
+ * The policy network's input for N states on the device: dqn.get_state_vector_from_base_state (dqn.py:389-446: the nearest cars_ahead /
+ * cars_behind vehicles in list order as (acceleration, speed [difference], gap, 1), zero tuples where there are fewer, then ego speed,
+ * acceleration, x, y; normalised by 9, MAX_SPEED, SENSOR_RADIUS, 300, 100), cast to float32 as the gym wrapper of the reference's RL
+ * library hands it to the network (ddpg.py:84: env._make_state), plus, if time_feature, the 21st input of ddpg.py:41 (TimeFeature of
+ * autonomous-learning-library 0.5.3): time_scale x d_evals[i] (policy evaluations of that episode so far), after which d_evals[i] counts
+ * one up -- for step > 1 only where the context's rollout (stmpc_rollout_step_device) is still going on, because the reference only asks
+ * its policy for those states.  The cast and the time feature restate a library that is absent from the reference checkout (parity
+ * unpinned); the other 20 entries are pinned to the reference's own function (tests/golden/golden_combined_real.npz).
+ * d_feat [N][feat_stride] float32, feat_stride >= stmpc_policy_features_len(cfg).  d_cur_oa may be NULL (accelerations read as 0).
+ */
+typedef struct stmpc_policy_features_cfg {
+    double max_speed;                /* Settings.MAX_SPEED */
+    double sensor_radius;            /* Settings.SENSOR_RADIUS */
+    double time_scale;               /* TimeFeature.scale: 0.001 */
+    int32_t cars_ahead, cars_behind; /* Settings.CARS_AHEAD, Settings.CARS_BEHIND */
+    int32_t use_acceleration;        /* Settings.USE_ACCELERATION_OF_OTHER_CARS */
+    int32_t use_speed_difference;    /* Settings.USE_SPEED_DIFFERENCE */
+    int32_t normalize;               /* Settings.NORMALIZE_VECTOR_INPUT */
+    int32_t time_feature;            /* 1: append the TimeFeature input (DDPG agents, ddpg.py:41) */
+} stmpc_policy_features_cfg;
+int stmpc_policy_features_len(const stmpc_policy_features_cfg *cfg);
+int stmpc_policy_features_device(stmpc_ctx *ctx, const stmpc_policy_features_cfg *cfg, int N, int Kmax, int step, const double *d_cur_ego4,
+                                 const int32_t *d_k_count, const double *d_cur_other_x, const double *d_cur_other_v, const double *d_cur_other_a,
+                                 int32_t *d_evals, float *d_feat, int feat_stride, void *stream);
+
 /* Host copies of the context's rollout bookkeeping and intermediate results (synchronises; any pointer may be NULL):
  * live, hist_len, crash_pred, have_test [N]; sel_speed [N]; rollout_s [N][rollout_length + 1]; test_ego4 [N][4], test_ox / test_ov [N][Kmax];
- * probe_crash [N], st_speed [N], fine [N][STMPC_QP_NMAX], fine_len [N] (valid after stmpc_combined_decide_device). */
+ * probe_crash [N], st_speed [N], fine [N][STMPC_QP_NMAX], fine_len [N] (valid after stmpc_combined_decide_device; with sparse_control st_speed is NaN and
+ * fine_len 0 for the states whose decision did not call the controller). */
 int stmpc_combined_read_state(stmpc_ctx *ctx, int N, int32_t *live, int32_t *hist_len, int32_t *crash_pred, double *sel_speed,
                               double *rollout_s, int32_t *have_test, double *test_ego4, double *test_ox, double *test_ov,
                               int32_t *probe_crash, double *st_speed, double *fine, int32_t *fine_len);

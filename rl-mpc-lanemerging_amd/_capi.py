@@ -55,14 +55,30 @@ class CombinedCfg(C.Structure):
     """``stmpc_combined_cfg`` (include/stmpc.h): the flags of dqn.RLAgent.do_combined_control."""
     _fields_ = [("tick_length", C.c_double), ("stop_x", C.c_double), ("rollout_length", C.c_int32), ("st_test_rollouts", C.c_int32),
                 ("check_rollout_crash", C.c_int32), ("limit_dqn_speed", C.c_int32), ("test_rollout_state", C.c_int32),
-                ("test_st_strictly_better", C.c_int32), ("remember_last_choice", C.c_int32)]
+                ("test_st_strictly_better", C.c_int32), ("remember_last_choice", C.c_int32), ("sparse_control", C.c_int32)]
 
     @classmethod
-    def from_settings(cls, S):
-        return cls(tick_length=S.TICK_LENGTH, stop_x=S.STOP_X, rollout_length=int(S.ROLLOUT_LENGTH), st_test_rollouts=int(S.ST_TEST_ROLLOUTS),
+    def from_settings(cls, S, sparse_control=True):
+        """``sparse_control`` (not a reference flag): solve st.do_st_control only for the states whose decision calls it, as the reference does
+        (one host round trip per decide call); False keeps the call fully asynchronous and solves every state."""
+        return cls(sparse_control=int(bool(sparse_control)), tick_length=S.TICK_LENGTH, stop_x=S.STOP_X, rollout_length=int(S.ROLLOUT_LENGTH), st_test_rollouts=int(S.ST_TEST_ROLLOUTS),
                    check_rollout_crash=int(bool(S.CHECK_ROLLOUT_CRASH)), limit_dqn_speed=int(bool(getattr(S, "LIMIT_DQN_SPEED", False))),
                    test_rollout_state=int(bool(S.TEST_ROLLOUT_STATE)), test_st_strictly_better=int(bool(getattr(S, "TEST_ST_STRICTLY_BETTER", False))),
                    remember_last_choice=int(bool(getattr(S, "REMEMBER_LAST_CHOICE_FOR_SWITCHING_COMBINED", False))))
+
+
+class FeaturesCfg(C.Structure):
+    """``stmpc_policy_features_cfg`` (include/stmpc.h): the flags of dqn.get_state_vector_from_base_state (+ the TimeFeature input of ddpg.py:41)."""
+    _fields_ = [("max_speed", C.c_double), ("sensor_radius", C.c_double), ("time_scale", C.c_double), ("cars_ahead", C.c_int32), ("cars_behind", C.c_int32),
+                ("use_acceleration", C.c_int32), ("use_speed_difference", C.c_int32), ("normalize", C.c_int32), ("time_feature", C.c_int32)]
+
+    @classmethod
+    def from_settings(cls, S, time_feature=True):
+        g = lambda name, default: getattr(S, name, default)             # the reference's defaults (config.py:35,48-49,136-139)
+        return cls(max_speed=float(S.MAX_SPEED), sensor_radius=float(g("SENSOR_RADIUS", 125)), time_scale=0.001, cars_ahead=int(g("CARS_AHEAD", 2)),
+                   cars_behind=int(g("CARS_BEHIND", 2)), use_acceleration=int(bool(g("USE_ACCELERATION_OF_OTHER_CARS", True))),
+                   use_speed_difference=int(bool(g("USE_SPEED_DIFFERENCE", True))), normalize=int(bool(g("NORMALIZE_VECTOR_INPUT", True))),
+                   time_feature=int(bool(time_feature)))
 
 
 class SimCfg(C.Structure):
@@ -90,8 +106,9 @@ EXPORTS = (
     "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
     "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check", "stmpc_debug_predict_ms",
     "stmpc_abi_version", "stmpc_check_error", "stmpc_predict_batch_acc", "stmpc_sim_status_device",
+    "stmpc_policy_features_device", "stmpc_policy_features_len", "stmpc_combined_counts",
 )
-ABI_VERSION = 3     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
+ABI_VERSION = 4     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
 QP_NMAX = 64        # STMPC_QP_NMAX
 QP_MAXITERS = 10    # STMPC_QP_MAXITERS (solvers.options['maxiters'], st.py:17)
@@ -154,6 +171,9 @@ def load():
     lib.stmpc_rollout_step_device.argtypes = [vp, pp, cp, C.c_int, C.c_int, C.c_int] + [vp] * 7 + [vp]
     lib.stmpc_combined_decide_device.argtypes = [vp, pp, cp, C.c_int, C.c_int] + [vp] * 12 + [vp]
     sp = C.POINTER(SimCfg)
+    lib.stmpc_policy_features_len.argtypes = [C.POINTER(FeaturesCfg)]
+    lib.stmpc_policy_features_device.argtypes = [vp, C.POINTER(FeaturesCfg), C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int, vp]
+    lib.stmpc_combined_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
     lib.stmpc_sim_init_device.argtypes = [vp, sp, C.c_int, vp]
     lib.stmpc_sim_view_device.argtypes = [vp, sp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.stmpc_sim_step_device.argtypes = [vp, pp, sp, C.c_int, vp, vp]
@@ -414,6 +434,17 @@ class Context:
         self._chk(self._lib.stmpc_combined_decide_device(self._h, C.byref(params), C.byref(cfg), int(N), int(Kmax), d_ego5_start, d_k, d_ox_start,
                                                          d_ov_start, d_cur_ego4, d_cur_ox, d_cur_ov, d_first_action, d_last_choice_rl,
                                                          d_takeover, d_reason, d_speed, stream))
+
+    def policy_features_device(self, fcfg, N, Kmax, step, d_cur_ego4, d_k, d_cur_ox, d_cur_ov, d_cur_oa, d_evals, d_feat, feat_stride, stream=0):
+        """The policy's float32 input vectors (dqn.get_state_vector_from_base_state + TimeFeature) into ``d_feat`` [N][feat_stride]."""
+        self._chk(self._lib.stmpc_policy_features_device(self._h, C.byref(fcfg), int(N), int(Kmax), int(step), d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
+                                                         d_cur_oa, d_evals, d_feat, int(feat_stride), stream))
+
+    def combined_counts(self, reset=False):
+        """(decisions taken, controller solves run for them) since the last reset."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.stmpc_combined_counts(self._h, C.byref(a), C.byref(b), int(bool(reset))))
+        return int(a.value), int(b.value)
 
     # -- batched episode simulator --------------------------------------------------------------
     def sim_init(self, cfg, N, stream=0):

@@ -36,8 +36,11 @@ def _unpack(ego4, k, ox, ov, oa, i):
                         [float(x) for x in ox[i, :kk]], [float(x) for x in ov[i, :kk]], [float(x) for x in oa[i, :kk]])
 
 
-def decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_last_choice_rl=None, stream=0):
-    """One tick of ``do_combined_control`` for N states held in device tensors (torch, fp64 / int32), nothing leaves the GPU.
+def decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_last_choice_rl=None, stream=0, d_oa=None):
+    """One tick of ``do_combined_control`` for N states held in device tensors (torch, fp64 / int32), nothing leaves the GPU
+    (with ``cfg.sparse_control`` one integer does: the number of states whose decision calls the controller).
+    ``d_oa``: the other vehicles' accelerations of the start states (``HighwayState.other_accelerations``; read by the policy's state vector
+    only, dqn.py:399-400); zeros if not given.
 
     ``policy(step, cur_ego4, k, cur_ox, cur_ov, cur_oa) -> jerk[N]`` (fp64 device tensor) is the caller's network; it is asked once
     per rollout step for every episode (entries of episodes whose rollout has ended are ignored, dqn.py:129-141).  Returns device
@@ -47,7 +50,7 @@ def decide_batch_device(ctx, params, cfg, d_ego5, d_k, d_ox, d_ov, policy, d_las
     n, K = d_ego5.shape[0], d_ox.shape[1]
     cur_ego4 = d_ego5[:, :4].clone().contiguous()      # (a copy: with one row the slice is already contiguous and would alias the start state)
     cur_ox, cur_ov = d_ox.clone(), d_ov.clone()
-    cur_oa = torch.zeros_like(d_ox)
+    cur_oa = d_oa.clone() if d_oa is not None else torch.zeros_like(d_ox)
     first_action = None
     for step in range(1, max(int(cfg.rollout_length), 1) + 1):
         action = policy(step, cur_ego4, d_k, cur_ox, cur_ov, cur_oa).to(torch.float64).contiguous()

@@ -128,8 +128,11 @@ struct stmpc_ctx {
     DevBuf ckpt, resume_t, phase_prof, prio_key;
     // combined controller (stmpc_rollout_step_device / stmpc_combined_decide_device): rollout bookkeeping and probe / controller outputs
     DevBuf cc_live, cc_hist_len, cc_crash_pred, cc_have_test, cc_sel, cc_rollout_s, cc_test_ego, cc_test_ox, cc_test_ov, cc_probe_ego, cc_probe_ox, cc_probe_ov,
-        cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err;
+        cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err,
+        cc_sel_idx, cc_sel_count, cc_c_ego, cc_c_k, cc_c_ox, cc_c_ov, cc_c_speed, cc_c_fine, cc_c_fine_len;      // sparse controller solve: the states that need st.do_st_control
     int cc_N = 0, cc_K = 0, cc_R = 0;
+    int *cc_host_count = nullptr;  // pinned host word for the number of those states
+    int64_t cc_ticks = 0, cc_control_solves = 0;      // decisions taken / controller solves run for them (stmpc_combined_counts)
     // batched episode simulator (stmpc_sim_*)
     DevBuf sim_ego, sim_nveh, sim_vx, sim_vv, sim_va, sim_vc, sim_delay, sim_status, sim_ticks, sim_rng, sim_acc;
     int sim_N = 0;
@@ -344,8 +347,10 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
                      &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
                      &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
-                     &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed};
+                     &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed,
+                     &c->cc_sel_idx, &c->cc_sel_count, &c->cc_c_ego, &c->cc_c_k, &c->cc_c_ox, &c->cc_c_ov, &c->cc_c_speed, &c->cc_c_fine, &c->cc_c_fine_len};
     for (DevBuf *b : all) b->release();
+    if (c->cc_host_count) (void)hipHostFree(c->cc_host_count);
     if (c->main_masked) (void)hipStreamDestroy(c->main_masked);
     if (c->aux_reserved) (void)hipStreamDestroy(c->aux_reserved);
     if (c->ev_join0) (void)hipEventDestroy(c->ev_join0);
@@ -1468,6 +1473,48 @@ int stmpc_rollout_step_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_c
     return STMPC_OK;
 }
 
+int stmpc_policy_features_device(stmpc_ctx *c, const stmpc_policy_features_cfg *f, int N, int Kmax, int step, const double *d_cur_ego4, const int32_t *d_k,
+                                 const double *d_cur_ox, const double *d_cur_ov, const double *d_cur_oa, int32_t *d_evals, float *d_feat, int feat_stride, void *stream) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (!f) return fail(STMPC_EINVAL, "features cfg is NULL");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || step < 1) return fail(STMPC_EINVAL, "N, Kmax or step out of range");
+    if (f->cars_ahead < 0 || f->cars_behind < 0 || f->cars_ahead > STMPC_KMAX_LIMIT || f->cars_behind > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "cars_ahead / cars_behind out of range");
+    const int len = stmpc_policy_features_len(f);
+    if (feat_stride < len) return fail(STMPC_EINVAL, "feat_stride is shorter than the feature vector");
+    if (f->normalize && (!(f->max_speed > 0) || !(f->sensor_radius > 0))) return fail(STMPC_EINVAL, "max_speed and sensor_radius must be positive");
+    if (N == 0) return STMPC_OK;
+    if (!d_cur_ego4 || !d_k || !d_feat) return fail(STMPC_EINVAL, "NULL device pointer");
+    if (Kmax > 0 && (!d_cur_ox || !d_cur_ov)) return fail(STMPC_EINVAL, "NULL device pointer (vehicles)");
+    if (f->time_feature && !d_evals) return fail(STMPC_EINVAL, "time_feature needs the evaluation counters");
+    const int *live = nullptr;
+    if (step > 1) {                // later rollout steps: only states whose rollout is still going on are evaluated by the reference (dqn.py:129-133)
+        if (c->cc_N != N) return fail(STMPC_EINVAL, "step > 1 without a rollout of this size in the context (stmpc_rollout_step_device)");
+        live = c->cc_live.as<int>();
+    }
+    HIPCHK(hipSetDevice(c->device));
+    FeatCfg fc;
+    fc.max_speed = f->max_speed; fc.sensor_radius = f->sensor_radius; fc.time_scale = (float)f->time_scale;
+    fc.cars_ahead = f->cars_ahead; fc.cars_behind = f->cars_behind; fc.use_accel = f->use_acceleration != 0; fc.use_speed_diff = f->use_speed_difference != 0;
+    fc.normalize = f->normalize != 0; fc.time_feature = f->time_feature != 0;
+    hipLaunchKernelGGL(k_policy_features, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, fc, N, Kmax, d_cur_ego4, d_k, d_cur_ox, d_cur_ov, d_cur_oa, live,
+                       d_evals, d_feat, feat_stride);
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
+}
+
+int stmpc_policy_features_len(const stmpc_policy_features_cfg *f) {
+    if (!f) return 0;
+    return (f->cars_ahead + f->cars_behind) * (f->use_acceleration ? 4 : 3) + 4 + (f->time_feature ? 1 : 0);
+}
+
+int stmpc_combined_counts(stmpc_ctx *c, int64_t *decisions, int64_t *control_solves, int reset) {
+    if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
+    if (decisions) *decisions = c->cc_ticks;
+    if (control_solves) *control_solves = c->cc_control_solves;
+    if (reset) { c->cc_ticks = 0; c->cc_control_solves = 0; }
+    return STMPC_OK;
+}
+
 int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_combined_cfg *g, int N, int Kmax,
                                  const double *d_ego5_start, const int32_t *d_k, const double *d_ox_start, const double *d_ov_start,
                                  const double *d_cur_ego4, const double *d_cur_ox, const double *d_cur_ov, const double *d_first_action,
@@ -1509,8 +1556,45 @@ int stmpc_combined_decide_device(stmpc_ctx *c, const stmpc_params *p, const stmp
     }
     // 2. the controller on the start state (st.do_st_control; also the path of the strictly-better comparison, dqn.py:157-164)
     HIPCHK(hipMemsetAsync(c->cc_fine.p, 0, (size_t)N * STMPC_QP_NMAX * 8, st_));
-    if ((rc = st_control_device(c, p, g->tick_length, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(),
-                                c->cc_cost.as<double>(), c->cc_speed.as<double>(), c->cc_fine.as<double>(), c->cc_fine_len.as<int32_t>(), stream, nullptr))) return rc;
+    c->cc_ticks += N;
+    if (g->sparse_control && !cc.strictly_better) {
+        // The reference solves the start state only when a branch of dqn.py:144-155 hands control over (2-5 % of the ticks under the shipped
+        // configs); here: ordered compaction of those states, ONE host round trip for their number, the controller on the compact batch, scatter.
+        if ((rc = c->cc_sel_idx.ensure((size_t)N * 4))) return rc;
+        if ((rc = c->cc_sel_count.ensure(4))) return rc;
+        if (!c->cc_host_count) HIPCHK(hipHostMalloc((void **)&c->cc_host_count, 4, hipHostMallocDefault));
+        HIPCHK(hipMemsetAsync(c->cc_speed.p, 0xFF, (size_t)N * 8, st_));            // NaN: no controller command exists for a state the policy keeps
+        HIPCHK(hipMemsetAsync(c->cc_fine_len.p, 0, (size_t)N * 4, st_));
+        hipLaunchKernelGGL(k_cc_select, dim3(1), dim3(1024), 0, st_, cc, N, st, (const int *)c->cc_pcrash.as<int>(), c->cc_sel_idx.as<int>(), c->cc_sel_count.as<int>());
+        HIPCHK(hipMemcpyAsync(c->cc_host_count, c->cc_sel_count.p, 4, hipMemcpyDeviceToHost, st_));
+        HIPCHK(hipStreamSynchronize(st_));
+        const int M = *c->cc_host_count;
+        if (M < 0 || M > N) return fail(STMPC_EINTERNAL, "combined controller: selection count out of range");
+        c->cc_control_solves += M;
+        if (M > 0) {
+            if ((rc = c->cc_c_ego.ensure((size_t)M * 5 * 8))) return rc;
+            if ((rc = c->cc_c_k.ensure((size_t)M * 4))) return rc;
+            if ((rc = c->cc_c_ox.ensure((size_t)M * Kalloc * 8))) return rc;
+            if ((rc = c->cc_c_ov.ensure((size_t)M * Kalloc * 8))) return rc;
+            if ((rc = c->cc_c_speed.ensure((size_t)M * 8))) return rc;
+            if ((rc = c->cc_c_fine.ensure((size_t)M * STMPC_QP_NMAX * 8))) return rc;
+            if ((rc = c->cc_c_fine_len.ensure((size_t)M * 4))) return rc;
+            const int mb = (M + 63) / 64;
+            hipLaunchKernelGGL(k_cc_gather, dim3(mb), dim3(64), 0, st_, M, Kalloc, Kmax, (const int *)c->cc_sel_idx.as<int>(), d_ego5_start, d_k, d_ox_start, d_ov_start,
+                               c->cc_c_ego.as<double>(), c->cc_c_k.as<int>(), c->cc_c_ox.as<double>(), c->cc_c_ov.as<double>());
+            HIPCHK(hipMemsetAsync(c->cc_c_fine.p, 0, (size_t)M * STMPC_QP_NMAX * 8, st_));
+            if ((rc = st_control_device(c, p, g->tick_length, M, Kalloc, c->cc_c_ego.as<double>(), c->cc_c_k.as<int32_t>(), c->cc_c_ox.as<double>(), c->cc_c_ov.as<double>(),
+                                        c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(), c->cc_cost.as<double>(), c->cc_c_speed.as<double>(), c->cc_c_fine.as<double>(),
+                                        c->cc_c_fine_len.as<int32_t>(), stream, nullptr))) return rc;
+            hipLaunchKernelGGL(k_cc_scatter, dim3(mb), dim3(64), 0, st_, M, (const int *)c->cc_sel_idx.as<int>(), (const double *)c->cc_c_speed.as<double>(),
+                               (const double *)c->cc_c_fine.as<double>(), (const int *)c->cc_c_fine_len.as<int>(), STMPC_QP_NMAX, c->cc_speed.as<double>(),
+                               c->cc_fine.as<double>(), c->cc_fine_len.as<int>());
+        }
+    } else {
+        c->cc_control_solves += N;
+        if ((rc = st_control_device(c, p, g->tick_length, N, Kmax, d_ego5_start, d_k, d_ox_start, d_ov_start, c->cc_path.as<int32_t>(), c->cc_bt.as<int32_t>(),
+                                    c->cc_cost.as<double>(), c->cc_speed.as<double>(), c->cc_fine.as<double>(), c->cc_fine_len.as<int32_t>(), stream, nullptr))) return rc;
+    }
     // 3. the decision
     hipLaunchKernelGGL(k_cc_decide, dim3(blocks), dim3(64), 0, st_, cc, N, d_ego5_start, d_first_action, d_last_choice_rl, st, (const int *)c->cc_pcrash.as<int>(),
                        (const double *)c->cc_speed.as<double>(), (const double *)c->cc_fine.as<double>(), (const int *)c->cc_fine_len.as<int>(), STMPC_QP_NMAX,

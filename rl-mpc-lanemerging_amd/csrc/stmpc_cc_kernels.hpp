@@ -154,6 +154,101 @@ __global__ void __launch_bounds__(64) k_cc_decide(CCfg c, int N, const double *_
     speed_out[e] = speed;
 }
 
+// The policy's input vector for N states: dqn.get_state_vector_from_base_state (dqn.py:389-446), then what the reference's RL library does
+// between that function and the network in DDPGAgent.get_control (ddpg.py:83-87) -- GymEnvironment._make_state's cast to the observation
+// space's float32, and TimeFeature (ddpg.py:41), which appends 0.001 x (policy evaluations since the episode began) and counts one up.
+// The library (`all` 0.5.3) is absent from the reference checkout: the cast and the time feature are restated from its published source
+// and are parity-unpinned; the 20 entries before them are the reference's own function and are pinned by golden_combined_real.npz.
+// One thread per state.  Vehicles are taken in LIST order as the reference takes them (front list reversed, dqn.py:417), not sorted.
+struct FeatCfg {
+    double max_speed, sensor_radius;      // Settings.MAX_SPEED, Settings.SENSOR_RADIUS
+    float time_scale;                     // TimeFeature.scale (0.001)
+    int cars_ahead, cars_behind, use_accel, use_speed_diff, normalize, time_feature;
+};
+__global__ void __launch_bounds__(64) k_policy_features(FeatCfg f, int N, int Kmax, const double *__restrict__ ego4, const int *__restrict__ k_count,
+                                                        const double *__restrict__ ox, const double *__restrict__ ov, const double *__restrict__ oa,
+                                                        const int *__restrict__ live /* null: every state is evaluated */, int *evals, float *feat, int stride) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const double ex = ego4[(size_t)e * 4 + 0], ey = ego4[(size_t)e * 4 + 1], ev = ego4[(size_t)e * 4 + 2], ea = ego4[(size_t)e * 4 + 3];
+    int k = k_count[e];
+    k = k < 0 ? 0 : (k > Kmax ? Kmax : k);
+    const int tw = f.use_accel ? 4 : 3;
+    float *row = feat + (size_t)e * stride;
+    const int nveh = (f.cars_ahead + f.cars_behind) * tw;
+    for (int q = 0; q < nveh; ++q) row[q] = 0.0f;                              // buffer tuples (dqn.py:418-425)
+    const double *xs = ox + (size_t)e * Kmax, *vs = ov + (size_t)e * Kmax, *as = oa ? oa + (size_t)e * Kmax : nullptr;
+    auto put = [&](int slot, int i) {
+        float *t = row + slot * tw;
+        int o = 0;
+        if (f.use_accel) { const double a = as ? as[i] : 0.0; t[o++] = (float)(f.normalize ? a / 9.0 : a); }
+        const double dv = f.use_speed_diff ? vs[i] - ev : vs[i];
+        t[o++] = (float)(f.normalize ? dv / f.max_speed : dv);
+        const double dx = xs[i] - ex;
+        t[o++] = (float)(f.normalize ? dx / f.sensor_radius : dx);
+        t[o] = 1.0f;
+    };
+    int nf = 0, nb = 0;
+    for (int i = k - 1; i >= 0 && nf < f.cars_ahead; --i) if (xs[i] > ex) put(nf++, i);                // front_cars reversed, first CARS_AHEAD
+    for (int i = 0; i < k && nb < f.cars_behind; ++i) if (!(xs[i] > ex)) put(f.cars_ahead + nb++, i);  // back_cars, first CARS_BEHIND
+    float *t = row + nveh;
+    t[0] = (float)(f.normalize ? ev / f.max_speed : ev);
+    t[1] = (float)(f.normalize ? ea / 9.0 : ea);
+    t[2] = (float)(f.normalize ? ex / 300.0 : ex);
+    t[3] = (float)(f.normalize ? ey / 100.0 : ey);
+    if (f.time_feature) {
+        const int n = evals[e];
+        t[4] = f.time_scale * (float)n;                                       // scale * timestep, single precision as torch evaluates it
+        if (!live || live[e]) evals[e] = n + 1;                               // only the states whose rollout goes on ask the policy again (dqn.py:129-133)
+    }
+}
+
+// Ordered list of the states whose decision needs st.do_st_control(start_state) (dqn.py:144-155; every branch but the
+// strictly-better comparison, which needs the controller's path for every state).  One workgroup, block-wide ordered compaction.
+__global__ void __launch_bounds__(1024) k_cc_select(CCfg c, int N, CCState st, const int *__restrict__ probe_crash, int *sel_idx, int *sel_count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < N; start += 1024) {
+        const int e = start + tid;
+        bool need = false;
+        if (e < N) need = (c.check_rollout_crash && st.crash_pred[e]) || (c.limit_speed && st.sel_speed[e] > c.desired_speed) || (c.test_rollout_state && probe_crash[e]);
+        const unsigned long long b = __ballot(need);
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        if (need) sel_idx[off + __popcll(b & ((1ull << lane) - 1ull))] = e;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += wsum[i]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *sel_count = base;
+}
+__global__ void __launch_bounds__(64) k_cc_gather(int M, int Kmax, int Kcopy, const int *__restrict__ sel_idx, const double *__restrict__ ego5, const int *__restrict__ k_count,
+                                                  const double *__restrict__ ox, const double *__restrict__ ov, double *c_ego5, int *c_k, double *c_ox, double *c_ov) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const int e = sel_idx[j];
+    for (int q = 0; q < 5; ++q) c_ego5[(size_t)j * 5 + q] = ego5[(size_t)e * 5 + q];
+    c_k[j] = k_count[e];
+    for (int i = 0; i < Kmax; ++i) {
+        c_ox[(size_t)j * Kmax + i] = i < Kcopy ? ox[(size_t)e * Kcopy + i] : 0.0;
+        c_ov[(size_t)j * Kmax + i] = i < Kcopy ? ov[(size_t)e * Kcopy + i] : 0.0;
+    }
+}
+__global__ void __launch_bounds__(64) k_cc_scatter(int M, const int *__restrict__ sel_idx, const double *__restrict__ c_speed, const double *__restrict__ c_fine,
+                                                   const int *__restrict__ c_fine_len, int fine_stride, double *speed, double *fine, int *fine_len) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const int e = sel_idx[j];
+    speed[e] = c_speed[j];
+    fine_len[e] = c_fine_len[j];
+    for (int q = 0; q < fine_stride; ++q) fine[(size_t)e * fine_stride + q] = c_fine[(size_t)j * fine_stride + q];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // SUMO-free batched merge episodes (stands in for control.run_episode / control.step,
 // control.py:215-340).  The traffic is the reference's "simple traffic distribution" (config.py:39, sumo.py:43-58): vehicles of

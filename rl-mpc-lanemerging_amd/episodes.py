@@ -60,7 +60,7 @@ class EpisodeRunner:
         dev = torch.device("cuda", torch.cuda.current_device())
         H = _capi.num_t(self.params)
         z = lambda *shape, dtype=torch.float64: torch.zeros(shape, dtype=dtype, device=dev)
-        self.d_ego5, self.d_k, self.d_ox, self.d_ov = z(n, 5), z(n, dtype=torch.int32), z(n, kmax), z(n, kmax)
+        self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.d_oa = z(n, 5), z(n, dtype=torch.int32), z(n, kmax), z(n, kmax), z(n, kmax)
         self.d_path, self.d_bt, self.d_cost, self.d_speed = z(n, H, dtype=torch.int32), z(n, dtype=torch.int32), z(n), z(n)
         self.d_fine, self.d_fine_len = z(n, _capi.QP_NMAX), z(n, dtype=torch.int32)
         self.ccfg = _capi.CombinedCfg.from_settings(Settings) if controller == "combined" else None
@@ -74,14 +74,15 @@ class EpisodeRunner:
         """Planner view -> controller -> world step for every environment (finished environments idle)."""
         from . import combined
         torch, ctx, n, kmax = self.torch, self.ctx, self.n, self.kmax
-        ctx.sim_view(self.cfg, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr())
+        ctx.sim_view(self.cfg, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr(),
+                     self.d_oa.data_ptr() if self.controller == "combined" else 0)
         if self.controller == "st":
             ctx.st_control_batch_device(self.params, self.tick_length, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr(),
                                         self.d_path.data_ptr(), self.d_bt.data_ptr(), self.d_cost.data_ptr(), self.d_speed.data_ptr(), self.d_fine.data_ptr(),
                                         self.d_fine_len.data_ptr(), 0)
             cmd = self.d_speed
         else:
-            d = combined.decide_batch_device(ctx, self.params, self.ccfg, self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.policy, self.last_rl)
+            d = combined.decide_batch_device(ctx, self.params, self.ccfg, self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.policy, self.last_rl, d_oa=self.d_oa)
             cmd = d["speed"]
             # per-episode takeover share (the reference's stats count the ticks of the episode itself): finished environments keep
             # returning their final state from sim_view, their repeated decisions must not be counted

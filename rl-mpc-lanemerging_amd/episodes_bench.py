@@ -6,7 +6,7 @@ reward of dqn.py:449-460 is a closed-form expression), so nothing here has a ref
 What can be measured is the environment side such a training loop would run on this stack: N merge environments with
 train_moderate_1.json's traffic (BASE_TRAFFIC_INTERVAL 1.2 s, OTHER_CAR_SPEED 11 m/s), stepped in lock-step on the device by the
 combined RL + MPC controller (policy rollout, feasibility probe solve, controller solve + QP re-sampling, decision,
-``combined.decide_batch_device``) with the STAND-IN actor of ``combined_bench`` in place of a learner.  A step = one simulator tick of
+``combined.decide_batch_device``) with the reference's pretrained actor for that traffic (``runs/ddpg_moderate1_extended``, ``actor.DDPGActor``) in place of a learner.  A step = one simulator tick of
 every environment; the value is environment steps per second.
 """
 import time
@@ -26,7 +26,8 @@ def run(args, rank, world, dev, dist):
     S = pkg.Settings
     n = args.episodes if args.episodes > 0 else 4096
     ctx = _capi.Context(dev.index or 0)
-    policy = combined_bench.make_stand_in_policy(torch, S, dev)
+    from rl_mpc_lanemerging_amd import actor as actor_mod
+    policy = actor_mod.DDPGActor("runs/ddpg_moderate1_extended", n, ctx, S, dev)       # configs/combined_moderate_1.json:4, trained on this traffic (train_moderate_1.json)
     r = episodes.EpisodeRunner(n, seed=5000 + rank, controller="combined", policy=policy, ctx=ctx, kmax=16)
     for _ in range(args.warmup):
         r.tick()
@@ -50,7 +51,7 @@ def run(args, rank, world, dev, dist):
             "value": n * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "reference_counterpart": False,
-            "config": {"workload": "N=%d environments/GPU in lock-step, every tick: planner view, %d-step policy rollout (STAND-IN 21-400-300-1 actor), feasibility "
+            "config": {"workload": "N=%d environments/GPU in lock-step, every tick: planner view, %d-step policy rollout (pretrained ddpg_moderate1 actor), feasibility "
                                    "probe solve, controller solve (H=%d, S=%d) + QP re-sampling, decision, world step (Krauss traffic %.1f s / %.0f m/s)"
                                    % (n, max(int(S.ROLLOUT_LENGTH), 1), _capi.num_t(r.params), _capi.num_s(r.params, 0.0), S.BASE_TRAFFIC_INTERVAL, S.OTHER_CAR_SPEED),
                        "episodes_per_gpu": n, "note": "BASELINE configs[4] has no counterpart in the reference (its training never calls the solver, SURVEY R7): demo only"},

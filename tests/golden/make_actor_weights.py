@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Export the reference's pretrained DDPG actors as raw tensors (data only, no pickle, no reference source).
+
+Build-container only (needs /root/reference/pretrained_models).  The checkpoints are ``torch.save``d modules of the
+``all`` library (autonomous-learning-library 0.5.3, requirements.txt:10), which is not installed; the two classes the
+pickle names -- ``all.policies.deterministic.DeterministicPolicyNetwork`` and ``all.nn.Linear0`` -- are mapped to inert
+``nn.Module`` stand-ins by a ``find_class`` override, which is enough to read the tensors and the two squash constants:
+
+    model.0  Linear 21 -> 400      (ddpg.py:29-41: the ``all`` ddpg preset's fc_deterministic_policy)
+    model.2  Linear 400 -> 300
+    model.4  Linear0 300 -> 1      (an nn.Linear initialised to zero)
+    output = tanh(model(x)) * _tanh_scale + _tanh_mean     (action space Box(MINIMUM_NEGATIVE_JERK, MAXIMUM_POSITIVE_JERK), merge_gym.py:220-222)
+
+Writes tests/golden/actor_ddpg_<name>.npz with w0,b0,w1,b1,w2,b2 (float32, as stored), tanh_scale, tanh_mean.
+Re-run:  python tests/golden/make_actor_weights.py
+"""
+import os
+import pickle
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_MODELS = "/root/reference/pretrained_models"
+NAMES = ["low1", "medium1", "default1", "moderate1", "fast1"]
+
+
+class _Inert(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            if not module.startswith("all."):
+                raise
+            return type(name, (_Inert,), {"__module__": module})
+
+
+def load_policy(path):
+    pm = types.ModuleType("pickle_with_stand_ins")
+    pm.Unpickler = _Unpickler
+    pm.load = lambda f, **kw: _Unpickler(f, **kw).load()
+    pm.__name__ = "pickle"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return torch.load(path, pickle_module=pm, weights_only=False, map_location="cpu")
+
+
+def main():
+    for name in NAMES:
+        m = load_policy(os.path.join(REF_MODELS, "ddpg_%s_extended" % name, "policy.pt"))
+        sd = m.state_dict()
+        assert list(sd) == ["model.0.weight", "model.0.bias", "model.2.weight", "model.2.bias", "model.4.weight", "model.4.bias"], list(sd)
+        kinds = [type(x).__name__ for x in m._modules["model"]._modules.values()]
+        assert kinds == ["Linear", "ReLU", "Linear", "ReLU", "Linear0"], kinds
+        scale, mean = m.__dict__["_tanh_scale"], m.__dict__["_tanh_mean"]
+        scale = float(scale.item() if hasattr(scale, "item") else scale)
+        mean = float(mean.item() if hasattr(mean, "item") else mean)
+        out = os.path.join(HERE, "actor_ddpg_%s.npz" % name)
+        np.savez_compressed(out, w0=sd["model.0.weight"].numpy(), b0=sd["model.0.bias"].numpy(), w1=sd["model.2.weight"].numpy(),
+                            b1=sd["model.2.bias"].numpy(), w2=sd["model.4.weight"].numpy(), b2=sd["model.4.bias"].numpy(),
+                            tanh_scale=np.float64(scale), tanh_mean=np.float64(mean))
+        print(name, {k: tuple(v.shape) for k, v in sd.items()}, "tanh_scale", scale, "tanh_mean", mean, "->", os.path.getsize(out), "B")
+
+
+if __name__ == "__main__":
+    main()

@@ -49,17 +49,17 @@ def test_st_episodes_match_the_reference_statistically(interval, gpu_ctx, restor
 def test_combined_controller_environments_config5_demo(gpu_ctx, restore_settings):
     """BASELINE configs[4] (configs/train_moderate_1.json) has no counterpart in the reference (its training never calls the solver): what
     exists is the environment side -- batched merge environments with that config's traffic under the combined RL + MPC controller
-    (stand-in actor).  64 environments for 50 ticks: deterministic, and the status / tick bookkeeping is consistent."""
+    (the reference's pretrained actor for that traffic).  64 environments for 50 ticks: deterministic, and the status / tick bookkeeping is consistent."""
     import torch
     import rl_mpc_lanemerging_amd as pkg
-    from rl_mpc_lanemerging_amd import combined_bench, episodes, episodes_bench
+    from rl_mpc_lanemerging_amd import actor, combined_bench, episodes, episodes_bench
     pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
     pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1)
     pkg.apply_overrides(episodes_bench.TRAIN_MODERATE_1_ENV)
     dev = torch.device("cuda", torch.cuda.current_device())
     runs = []
     for _ in range(2):
-        policy = combined_bench.make_stand_in_policy(torch, pkg.Settings, dev)
+        policy = actor.DDPGActor("runs/ddpg_moderate1_extended", 64, gpu_ctx, pkg.Settings, dev)
         runs.append(episodes.run_episodes(64, seed=11, controller="combined", policy=policy, ctx=gpu_ctx, kmax=16, max_ticks=50))
     a, b = runs
     for key in ("status", "ticks", "ego4", "mean_speed", "percent_st"):
