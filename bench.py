@@ -201,6 +201,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
     d_pd = torch.empty((n, H), dtype=torch.float64, device=dev)
     d_crash = torch.empty(n, dtype=torch.int32, device=dev)
     gathered = torch.empty((n * world, 2), dtype=torch.float64, device=dev) if use_dist else None
+    d_ac = torch.empty((n, 2), dtype=torch.float64, device=dev) if use_dist else None      # fused (action, cost) rows, written by the solver's back-track
     control = args.workload == "control"
     d_speed = torch.empty(n, dtype=torch.float64, device=dev) if control else None
     d_fine = torch.zeros((n, _capi.QP_NMAX), dtype=torch.float64, device=dev) if control else None
@@ -215,9 +216,11 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         else:
             ctx.solve_batch_device(params, n, Kmax, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(),
                                    d_path.data_ptr(), d_bt.data_ptr(), d_cost.data_ptr(), d_pd.data_ptr(),
-                                   d_crash.data_ptr(), stream)
+                                   d_crash.data_ptr(), stream, d_ac.data_ptr() if use_dist else 0)
         if use_dist:
-            sharding.gather_actions(sharding.pack_actions(d_path, d_cost), world, gathered, force=True)
+            if control:
+                d_ac.copy_(sharding.pack_actions(d_path, d_cost))       # (the controller entry has no fused output)
+            sharding.gather_actions(d_ac, world, gathered, force=True)   # the step's one collective, on the buffer the solver wrote
 
     def barrier():
         if use_dist:
@@ -257,12 +260,14 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         o_cost = torch.empty(n_, dtype=torch.float64, device=dev); o_pd = torch.empty((n_, H), dtype=torch.float64, device=dev)
         o_crash = torch.empty(n_, dtype=torch.int32, device=dev)
         g_ = torch.empty((n_ * world, 2), dtype=torch.float64, device=dev) if use_dist else None
+        ac_ = torch.empty((n_, 2), dtype=torch.float64, device=dev) if use_dist else None
 
         def step_():
             ctx.solve_batch_device(params, n_, Kmax, te.data_ptr(), tk.data_ptr(), tx.data_ptr(), tv.data_ptr(), o_path.data_ptr(), o_bt.data_ptr(),
-                                   o_cost.data_ptr(), o_pd.data_ptr(), o_crash.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                   o_cost.data_ptr(), o_pd.data_ptr(), o_crash.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                   ac_.data_ptr() if use_dist else 0)
             if use_dist:
-                sharding.gather_actions(sharding.pack_actions(o_path, o_cost), world, g_, force=True)
+                sharding.gather_actions(ac_, world, g_, force=True)
         for _ in range(max(args.warmup, 1)):
             step_()
         barrier()
@@ -363,6 +368,7 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
            "roofline": roofline, "device_ms_per_step": prof["solve_ms"] / max(prof["launches"], 1),
            "tiers": {"first_lds_window": int(tier_stats["fast_path"]), "larger_lds_window": int(tier_stats["fallback"] - tier_stats["hbm_tier"]),
                      "hbm_scratch": int(tier_stats["hbm_tier"]), "bound_retries": int(tier_stats["retries"]), "guided_bounds": int(tier_stats.get("guided", 0)),
+                     "resume_refused": int(tier_stats.get("resume_refused", 0)),
                      "nodes_expanded_per_solve": (tier_stats["nodes_exact"] + tier_stats["nodes_bound"]) / n}}
 
     if pipelined:

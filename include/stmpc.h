@@ -28,9 +28,11 @@
  *
  * Concurrency: a context owns one set of scratch buffers, work counters and overflow queues; AT MOST ONE batched call may be
  * in flight per context (calls on one stream are naturally ordered; calls on different streams, or from different host
- * threads, need a context each).  The "_device" entries are asynchronous with respect to the host only -- with one exception: the first
- * wide-lattice solve after a change of the dynamics or cost parameters rebuilds a small table on the host (a few ms) and waits for the
- * device once (hipDeviceSynchronize) before replacing the previous one; calls with unchanged parameters never synchronise.
+ * threads, need a context each).  The "_device" entries are asynchronous with respect to the host -- with these exceptions: the first
+ * wide-lattice solve with a set of dynamics / cost parameters builds a small table on the host (a few ms; its upload is queued on the call's
+ * stream, so that call cannot be captured in a hipGraph) -- the context keeps the tables of the four most recent parameter sets, so alternating
+ * sets neither rebuild nor wait, and only a fifth set waits for the device (hipDeviceSynchronize) before it replaces the least recently used;
+ * and stmpc_combined_decide_device with sparse_control (one integer comes back to the host, see stmpc_combined_cfg).
  * Environment knobs (STMPC_*) are read once, in stmpc_create.
  * Scratch: the wide-lattice solver keeps one back-pointer per lattice cell of the first window and time layer per episode when it may continue
  * an overflowing search in the next window -- one byte (the distance to the predecessor) when no step of the dynamics exceeds 255 cells, else
@@ -119,6 +121,9 @@ typedef struct stmpc_stats {
     double  solve_ms;        /* device time of the last batch (HIP events on the launch stream) */
     double  dp_kernel_ms;    /* device time of the LDS lattice-DP kernel launches (all LDS tiers) */
     int64_t guided;          /* episodes whose bound came from the guided attempt (a tube around the unobstructed optimum) */
+    int64_t resume_refused;  /* 1: the batch wanted per-episode back-pointers + checkpoints (an overflowing search then continues in the wider window instead of
+                                starting over) and the memory rule turned them down -- they are taken only while they are at most a quarter of the device memory
+                                free at that moment (a process shared with torch / RCCL).  Same results, another schedule; re-priced every 64th call. */
 } stmpc_stats;
 
 /* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */
@@ -166,6 +171,15 @@ int stmpc_solve_batch_device(stmpc_ctx *ctx, const stmpc_params *p, int N, int K
                              const double *d_other_x, const double *d_other_v,
                              int32_t *d_path_idx, int32_t *d_best_t, double *d_cost,
                              double *d_path_dist, int32_t *d_crash, void *stream);
+
+/* The same solve with one more output for the multi-GPU gather: action_cost [N][2] fp64 = (path_idx[i][1] as a double -- the cell
+ * of the first step, the "action", -1.0 if the path ends at the start cell --, cost[i]) written by the solver's back-track itself, so that the
+ * sharded step hands ONE buffer to ONE collective without a packing pass.  d_action_cost may be NULL (= stmpc_solve_batch_device). */
+int stmpc_solve_batch_device_ac(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
+                                const double *d_ego, const int32_t *d_k_count,
+                                const double *d_other_x, const double *d_other_v,
+                                int32_t *d_path_idx, int32_t *d_best_t, double *d_cost,
+                                double *d_path_dist, int32_t *d_crash, double *d_action_cost, void *stream);
 
 /* Same with HOST pointers: stages H2D, solves, copies back, synchronises. */
 int stmpc_solve_batch(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax,
@@ -409,12 +423,6 @@ int stmpc_probe_arith(stmpc_ctx *ctx, int op, const double *a, const double *b, 
  * 0 if some x would round differently or the check cannot be completed -- the solver then divides with the ordinary IEEE sequence.
  * *zl (may be NULL) receives RN(1/d - RN(1/d)).  Host-only, no context. */
 int stmpc_fastdiv2_check(double d, double *zl);
-
-/* Analysis entry (profiles/, scripts/lab/predict_time.py): the average time in ms of `reps` launches of the traffic-prediction kernel alone
- * (prediction.py:22-105 + st.py:44-65 for the whole horizon) on DEVICE-resident states, Kmax <= 8.  mask 0: the whole kernel; 1: its serial
- * recurrence only, after which the context's vehicle table is not valid -- solve again before reading results. */
-int stmpc_debug_predict_ms(stmpc_ctx *ctx, const stmpc_params *p, int N, int Kmax, const double *d_ego, const int32_t *d_k,
-                           const double *d_other_x, const double *d_other_v, int reps, int mask, float *ms_out);
 
 #ifdef __cplusplus
 }

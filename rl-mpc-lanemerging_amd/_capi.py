@@ -48,7 +48,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("episodes", C.c_int64), ("fast_path", C.c_int64), ("fallback", C.c_int64), ("hbm_tier", C.c_int64),
                 ("retries", C.c_int64), ("nodes_exact", C.c_int64), ("nodes_bound", C.c_int64),
-                ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double), ("guided", C.c_int64)]
+                ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double), ("guided", C.c_int64), ("resume_refused", C.c_int64)]
 
 
 class CombinedCfg(C.Structure):
@@ -104,9 +104,9 @@ EXPORTS = (
     "stmpc_solve_grid", "stmpc_build_grid", "stmpc_predict_batch", "stmpc_probe_arith", "stmpc_profile",
     "stmpc_finer_fit_batch", "stmpc_st_control_batch", "stmpc_st_control_batch_device",
     "stmpc_rollout_step_device", "stmpc_combined_decide_device", "stmpc_combined_read_state", "stmpc_solve_grid_no_jerk",
-    "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check", "stmpc_debug_predict_ms",
+    "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check",
     "stmpc_abi_version", "stmpc_check_error", "stmpc_predict_batch_acc", "stmpc_sim_status_device",
-    "stmpc_policy_features_device", "stmpc_policy_features_len", "stmpc_combined_counts",
+    "stmpc_policy_features_device", "stmpc_policy_features_len", "stmpc_combined_counts", "stmpc_solve_batch_device_ac",
 )
 ABI_VERSION = 4     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
@@ -156,6 +156,7 @@ def load():
     lib.stmpc_path_mean_abs_jerk.restype = C.c_double
     lib.stmpc_fastdiv2_check.argtypes = [C.c_double, C.POINTER(C.c_double)]
     lib.stmpc_solve_batch_device.argtypes = [vp, pp, C.c_int, C.c_int] + [vp] * 9 + [vp]
+    lib.stmpc_solve_batch_device_ac.argtypes = [vp, pp, C.c_int, C.c_int] + [vp] * 10 + [vp]
     lib.stmpc_solve_batch.argtypes = [vp, pp, C.c_int, C.c_int, dp, ip, dp, dp, ip, ip, dp, dp, ip]
     lib.stmpc_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.stmpc_solve_grid.argtypes = [vp, u8p, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp] + [C.c_double] * 11 + [dp]
@@ -286,10 +287,11 @@ class Context:
 
     # -- batched solve, device pointers (ints), asynchronous ---------------------------------
     def solve_batch_device(self, params, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_pd=0, d_crash=0,
-                           stream=0):
-        self._chk(self._lib.stmpc_solve_batch_device(self._h, C.byref(params), int(N), int(Kmax), d_ego, d_k, d_ox,
-                                                     d_ov, d_path, d_bt, d_cost, d_pd or None, d_crash or None,
-                                                     stream or None))
+                           stream=0, d_action_cost=0):
+        """``d_action_cost``: optional fp64 [N][2] device buffer the solver fills with (first-step cell, cost) -- the fused row of the multi-GPU gather."""
+        self._chk(self._lib.stmpc_solve_batch_device_ac(self._h, C.byref(params), int(N), int(Kmax), d_ego, d_k, d_ox,
+                                                        d_ov, d_path, d_bt, d_cost, d_pd or None, d_crash or None,
+                                                        d_action_cost or None, stream or None))
 
     # -- st.finer_fit, batched (host arrays) ------------------------------------------------------
     def finer_fit_batch(self, params, delta_t, coarse_delta_t, s_seq, lengths, v0, a0, bac=None, maxiters=QP_MAXITERS):

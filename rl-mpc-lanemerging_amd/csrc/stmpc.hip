@@ -180,13 +180,20 @@ struct stmpc_ctx {
     // STMPC_CU_RESERVE=n (multiple of 8, experiment): n compute units are kept out of the first window's launch and host the second
     // window's workgroups from the start of the step (CU-masked streams); 0 = off
     int cu_reserve = 0;
+    int qp_maxiters = STMPC_QP_MAXITERS;   // STMPC_QP_ITERS (experiment: the iteration cap of st.do_st_control's QP; the reference's is 10, st.py:17)
     int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
-    std::vector<unsigned char> guide_host;
-    DevBuf guide_tab, guide_cells; double guide_key[12] = {0}; int guide_imax = 0, guide_D = 0, guide_H = 0; bool guide_ok = false, guide_key_valid = false;
+    // guide tables, one per parameter set (dynamics + cost weights), least recently used replaced: a caller that alternates parameter sets
+    // (two controllers on one context) neither rebuilds nor waits
+    struct GuideSlot { double key[12] = {0}; bool valid = false, ok = false; int imax = 0, D = 0; std::vector<unsigned char> host; DevBuf dev; uint64_t last_use = 0; };
+    GuideSlot guides[4]; uint64_t guide_clock = 0;
+    DevBuf guide_cells;
     int prio_thr = 32000;          // STMPC_PRIO=t (0 = off): an overflowing search with more than t (layers left x nodes of the saved layer) ahead of it is served first
                                    // by the second window (SolveArgs::prio_thr): 4.60 -> 4.46 ms over 12 seeds at N = 4096, flat from 25000 to 35000
     int prio_mode = 0;             // STMPC_PRIO_MODE (experiment: which estimate prio_thr is compared with)
     bool bp16 = false;             // STMPC_BP16=1: two-byte back-pointers even where one byte would do
+    unsigned resume_refused_calls = 0;
+    bool last_resume_refused = false;   // the last batch wanted checkpoint / resume and did not get it (stmpc_stats::resume_refused)
+    int64_t last_hbm_tier_count = 0;    // episodes the last batch whose statistics were read sent to the clean-up tier
     size_t resume_refused_for = 0; // back-pointer bytes of the last request the quarter-of-free-memory rule turned down (not asked again until the request changes)
     int retry_move = 0;            // STMPC_RETRY_MOVE=k: see SolveArgs::retry_move
     double retry_mult[3] = {1.05, 1.3, 4.0};    // STMPC_RETRY="a,b,c": growth of a bound that turned out to be below the reference's terminal cost.  Round 2 grew gently
@@ -295,6 +302,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_HEAVY_FIRST")) c->heavy_first = atoi(w) != 0;
     if (const char *w = getenv("STMPC_GSH")) { int v = atoi(w); if (v >= 0 && v <= 4) c->gsh_max = v; }
     if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_QP_ITERS")) { int v = atoi(w); if (v >= 0 && v <= 1000) c->qp_maxiters = v; }
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
     int prio_least = 0, prio_greatest = 0;
@@ -341,7 +349,8 @@ int stmpc_create(stmpc_ctx **out, int device) {
 void stmpc_destroy(stmpc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->guide_tab, &c->guide_cells, &c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
+    for (auto &g : c->guides) g.dev.release();
+    DevBuf *all[] = {&c->guide_cells, &c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
                      &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
@@ -535,7 +544,6 @@ int latch_solver_error(stmpc_ctx *c) {
     return STMPC_OK;
 }
 
-int g_pred_dbg = 0;      // (analysis: k_predict without its table rows, stmpc_debug_predict_ms only)
 template <int KMAX>
 void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const int *k, const double *ox, const double *ov,
                     CarTab tab, unsigned *counters, u64 *ubound, int *queue1, unsigned *proxy0, int *resume_t, unsigned char *prio_key, hipStream_t st,
@@ -543,7 +551,7 @@ void launch_predict(const DevP &dp, int N, int Kmax, const double *ego, const in
     constexpr int E = PredShape<KMAX>::E;          // episodes per wavefront (k_predict)
     int blocks = (N + E - 1) / E;
     hipLaunchKernelGGL(k_predict<KMAX>, dim3(blocks), dim3(128), 0, st, dp, N, Kmax, ego, k, ox, ov, tab, counters, ubound, queue1, proxy0, resume_t, prio_key, sticky,
-                       guide_tab, guide_imax, guide_D, guide, g_pred_dbg);
+                       guide_tab, guide_imax, guide_D, guide, 0);
 }
 
 }  // namespace
@@ -553,6 +561,12 @@ extern "C" {
 int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego,
                              const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
                              int32_t *d_bt, double *d_cost, double *d_pd, int32_t *d_crash, void *stream) {
+    return stmpc_solve_batch_device_ac(c, p, N, Kmax, d_ego, d_k, d_ox, d_ov, d_path, d_bt, d_cost, d_pd, d_crash, nullptr, stream);
+}
+
+int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego,
+                                const int32_t *d_k, const double *d_ox, const double *d_ov, int32_t *d_path,
+                                int32_t *d_bt, double *d_cost, double *d_pd, int32_t *d_crash, double *d_action_cost, void *stream) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
     if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "N or Kmax out of range");
     if (N == 0) return STMPC_OK;
@@ -632,7 +646,9 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         const bool cleanup_only = nt > 0 && tierW[nt - 1] >= Wg && !c->tiers_from_env && !c->force_general;
         tierW[nt] = Wg; tierPW[nt] = Wg; tierLds[nt] = false; tierNW[nt] = c->waves_override > 0 ? c->waves_override : 8;
         tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
-        tierGrid[nt] = cleanup_only ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
+        // (a batch that sent more than a handful of episodes there -- e.g. identical reset states whose second lattice point is not start + step --
+        // gets the full grid from the next step on)
+        tierGrid[nt] = (cleanup_only && c->last_hbm_tier_count <= 16) ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     }
     const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
@@ -646,13 +662,16 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     if (resume && c->bp_tier[0].cap < bp0_per_episode) {
         // a growing request: only while it is at most a quarter of what the device has free right now (a process shared with torch / RCCL).
         // A request that was turned down is not priced again (a driver round trip per step) until it changes.
-        if (c->resume_refused_for == bp0_per_episode) resume = false;
+        // ... but it is priced again every 64th call: memory another tenant held at that moment may be free by now.
+        if (c->resume_refused_for == bp0_per_episode && (++c->resume_refused_calls & 63) != 0) resume = false;
         else {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
             if (bp0_per_episode + (size_t)N * (16 + (size_t)tierW[0] * 12) > (free_b + c->bp_tier[0].cap) / 4) { resume = false; c->resume_refused_for = bp0_per_episode; }
+            else c->resume_refused_for = 0;
         }
     }
+    const bool resume_wanted = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1];
     const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
     // reserved compute units (experiment, STMPC_CU_RESERVE): the first window's persistent grid covers the remaining units only
     const bool reserve_cfg = c->cu_reserve > 0 && prune_on && nt >= 2 && tierLds[0] && tierLds[1] && !c->two_phase;
@@ -671,6 +690,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
         const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * bp_elem;
         if ((rc = c->bp_tier[k].ensure(need))) return rc;
     }
+    c->last_resume_refused = resume_wanted && !resume;
     int *resume_t = resume ? c->resume_t.as<int>() : nullptr;
     if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8)))) return rc;
 
@@ -696,30 +716,38 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     const bool heavy_first = split && c->heavy_first;
     if (heavy_first && (rc = c->prio_key.ensure((size_t)N))) return rc;
     unsigned char *prio_key = heavy_first ? c->prio_key.as<unsigned char>() : nullptr;
-    const unsigned char *g_tab = nullptr; u16 *g_cells = nullptr;
+    const unsigned char *g_tab = nullptr; u16 *g_cells = nullptr; int g_imax = 0, g_D = 0;
     if (prune_on && c->tube_w > 0) {
         // guided bounding attempt: the table depends on the dynamics and the cost weights only; rebuilt when they change (a few ms on the host)
         const double key[12] = {dp.ds, dp.dt, dp.v_w, dp.a_w, dp.j_w, dp.v_des, dp.v_max, dp.a_min, dp.a_max, dp.j_min, dp.j_max, (double)H};
-        if (!c->guide_key_valid || memcmp(key, c->guide_key, sizeof key) != 0) {
-            // A parameter change.  Kernels of earlier calls (on any stream) may still read the previous table and the staging buffer may
-            // still be in flight, so this path waits for the device once -- the only host synchronisation of this entry, documented in
-            // stmpc.h -- and the cache is marked valid only after the upload has been queued successfully.
-            c->guide_key_valid = false; c->guide_ok = false;
-            HIPCHK(hipDeviceSynchronize());
-            const bool built = build_guide_table(dp, c->guide_host, c->guide_imax, c->guide_D);
-            if (built) {
-                if ((rc = c->guide_tab.ensure(c->guide_host.size()))) return rc;
-                HIPCHK(hipMemcpy(c->guide_tab.p, c->guide_host.data(), c->guide_host.size(), hipMemcpyHostToDevice));
+        stmpc_ctx::GuideSlot *slot = nullptr;
+        for (auto &g : c->guides) if (g.valid && memcmp(key, g.key, sizeof key) == 0) { slot = &g; break; }
+        if (!slot) {
+            // A parameter set not seen before (or replaced since): build its table on the host (a few ms) and queue the upload on THIS call's
+            // stream, ahead of the kernels that read it.  Nothing waits for the device unless a table has to be replaced (a fifth parameter set):
+            // kernels of earlier calls may still read the one that goes.
+            for (auto &g : c->guides) if (!g.valid) { slot = &g; break; }
+            if (!slot) {
+                slot = &c->guides[0];
+                for (auto &g : c->guides) if (g.last_use < slot->last_use) slot = &g;
+                slot->valid = false;
+                HIPCHK(hipDeviceSynchronize());
             }
-            memcpy(c->guide_key, key, sizeof key);
-            c->guide_ok = built; c->guide_key_valid = true;
+            slot->ok = build_guide_table(dp, slot->host, slot->imax, slot->D);
+            if (slot->ok) {
+                if ((rc = slot->dev.ensure(slot->host.size()))) return rc;
+                HIPCHK(hipMemcpyAsync(slot->dev.p, slot->host.data(), slot->host.size(), hipMemcpyHostToDevice, st));
+            }
+            memcpy(slot->key, key, sizeof key);
+            slot->valid = true;                 // (only after the upload has been queued successfully)
         }
-        if (c->guide_ok) { if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc; g_tab = c->guide_tab.as<unsigned char>(); g_cells = c->guide_cells.as<u16>(); }
+        slot->last_use = ++c->guide_clock;
+        if (slot->ok) { if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc; g_tab = slot->dev.as<unsigned char>(); g_cells = c->guide_cells.as<u16>(); g_imax = slot->imax; g_D = slot->D; }
     }
     HIPCHK(hipEventRecord(e0, st));
-    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
-    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
-    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, c->guide_imax, c->guide_D, g_cells);
+    if (Kalloc <= 8) launch_predict<8>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, g_imax, g_D, g_cells);
+    else if (Kalloc <= 16) launch_predict<16>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, g_imax, g_D, g_cells);
+    else launch_predict<32>(dp, N, Kalloc, d_ego, d_k, d_ox, d_ov, tab, counters, c->ubound.as<u64>(), queue1, proxy0, resume_t, prio_key, st, c->sticky.as<unsigned>(), g_tab, g_imax, g_D, g_cells);
 
     SolveArgs a;
     memset(&a, 0, sizeof a);
@@ -762,7 +790,7 @@ int stmpc_solve_batch_device(stmpc_ctx *c, const stmpc_params *p, int N, int Kma
     a.maxshift = (int)ceil(dp.v_max * dp.dt / dp.ds) + 2 + 66;     // st_cy.pyx:65-93: v <= v_max; + interval rounding to 64-cell blocks
     a.proxy = c->proxy.as<unsigned>();
     const bool two_phase = a.prune && c->two_phase;      // bound all episodes first, then solve them heaviest-first
-    a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash;
+    a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash; a.action_cost = d_action_cost;
 
     if (overlap && split && c->retire_cus > 0 && c->retire_cus < c->num_cu) {
         if ((rc = c->cu_tab.ensure(1025 * sizeof(unsigned)))) return rc;
@@ -911,6 +939,8 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         c->stats.fallback = cnt[4];                       // episodes that overflowed the first LDS window
         c->stats.hbm_tier = (c->last_has_hbm && c->last_nt >= 2) ? cnt[4 * (c->last_nt - 1)] : 0;
         c->stats.fast_path = c->stats.episodes - cnt[4];
+        c->last_hbm_tier_count = c->stats.hbm_tier;
+        c->stats.resume_refused = c->last_resume_refused ? 1 : 0;
         c->stats.retries = cnt[STMPC_CNT_RETRY];
         c->stats.guided = cnt[STMPC_CNT_GUIDED];
         c->stats.nodes_exact = cnt[STMPC_CNT_NODES_EXACT];
@@ -926,39 +956,6 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         }
     }
     *out = c->stats;
-    return STMPC_OK;
-}
-
-// Analysis entry: time k_predict alone (reps launches between two events) on device-resident states; mask 1 = the recurrence only (no table
-// rows: the table is NOT valid afterwards).
-int stmpc_debug_predict_ms(stmpc_ctx *c, const stmpc_params *p, int N, int Kmax, const double *d_ego, const int32_t *d_k, const double *d_ox,
-                           const double *d_ov, int reps, int mask, float *ms_out) {
-    if (!c || !ms_out || N <= 0 || Kmax <= 0 || Kmax > 8 || reps < 1) return fail(STMPC_EINVAL, "bad argument");
-    HIPCHK(hipSetDevice(c->device));
-    DevP dp;
-    int rc = make_devp(p, &dp);
-    if (rc) return rc;
-    const int H = dp.H;
-    if ((rc = c->tab_edge.ensure((size_t)N * H * Kmax * 2 * sizeof(double)))) return rc;
-    if ((rc = c->tab_win.ensure((size_t)N * H * Kmax * 2 * sizeof(int)))) return rc;
-    if ((rc = c->tab_nact.ensure((size_t)N * H * sizeof(int)))) return rc;
-    if ((rc = c->tab_nums.ensure((size_t)N * sizeof(int)))) return rc;
-    if ((rc = c->counters.ensure(64 * sizeof(unsigned)))) return rc;
-    if ((rc = c->ubound.ensure((size_t)N * sizeof(u64)))) return rc;
-    if ((rc = c->guide_cells.ensure((size_t)N * H * sizeof(u16)))) return rc;
-    CarTab tab{c->tab_edge.as<double>(), c->tab_win.as<int>(), c->tab_nact.as<int>(), c->tab_nums.as<int>()};
-    const bool have_guide = c->guide_ok && c->guide_tab.p;
-    g_pred_dbg = mask & 1;
-    for (int r = 0; r < reps + 2; ++r) {
-        if (r == 2) HIPCHK(hipEventRecord(c->ev0, nullptr));
-        launch_predict<8>(dp, N, Kmax, d_ego, d_k, d_ox, d_ov, tab, c->counters.as<unsigned>(), c->ubound.as<u64>(), nullptr, nullptr, nullptr, nullptr, nullptr,
-                          c->sticky.as<unsigned>(), have_guide ? c->guide_tab.as<unsigned char>() : nullptr, c->guide_imax, c->guide_D, c->guide_cells.as<u16>());
-    }
-    g_pred_dbg = 0;
-    HIPCHK(hipEventRecord(c->ev1, nullptr));
-    HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
-    *ms_out /= (float)reps;
     return STMPC_OK;
 }
 
@@ -1338,7 +1335,7 @@ static int st_control_device(stmpc_ctx *c, const stmpc_params *p, double tick, i
     double tv[STMPC_MAXH];
     host_t_values(p, H, tv);
     // finer_fit is called with (TICK_LENGTH, T_DISCRETIZATION) = the settings, not the arange spacing (st.py:771-772)
-    if ((rc = make_ffconst(p, tick, p->dt, STMPC_QP_MAXITERS, &a.k))) return rc;
+    if ((rc = make_ffconst(p, tick, p->dt, c->qp_maxiters, &a.k))) return rc;
     a.N = N; a.Hs = H; a.n_max = STMPC_QP_NMAX; a.use_qp = (tick < p->dt) ? 1 : 0;
     a.path_idx = d_path; a.best_t = d_bt; a.ego = d_ego; a.ds = p->ds;
     a.out = d_fine; a.out_len = d_fine_len; a.speed = d_speed;

@@ -1,8 +1,9 @@
 // stmpc_kernels.hpp -- CDNA4 (gfx950) device code of the ST lattice solver.
 //
 // Design:
-//   k_predict : one THREAD per merge episode.  Runs the reference's traffic predictor
-//               (prediction.py:22-105) H-1 times and emits, per time layer, the list of
+//   k_predict : one workgroup of two wavefronts per 32 / KMAX merge episodes, one LANE per vehicle.  Wavefront 0 runs the
+//               reference's traffic predictor (prediction.py:22-105) H-1 times (the follower chain as repeated one-lane
+//               DPP shifts); wavefront 1 follows a layer group behind and emits, per time layer, the list of
 //               vehicles that obstruct the lattice (st.py:44-65): front/back edge and the
 //               blocked index window.  The H x S obstacle / distance grids of the reference
 //               are never materialised.
@@ -630,6 +631,10 @@ __device__ __forceinline__ double dev_weighted_penalty(double d, double min_allo
 // theorem: faithful q, exact residual by FMA, r = RN(1/d)) gives RN(x/d).  5 ops instead of the
 // ~12 of the generic v_div_scale/v_rcp/v_div_fmas/v_div_fixup expansion.  The FMAs here are
 // explicit; nothing else in this file may contract (-ffp-contract=off).
+// Cell offsets of the candidate filters, made safe for the conversion to int: clamped to +-1e9, a NaN reads as "no limit" on its side.
+__device__ __forceinline__ double cell_lo(double x) { return __builtin_fmin(__builtin_fmax(x, -1e9), 1e9); }
+__device__ __forceinline__ double cell_hi(double x) { return __builtin_fmax(__builtin_fmin(x, 1e9), -1e9); }
+
 template <bool FASTDIV>
 __device__ __forceinline__ double divc(double x, double d, double r) {
     if constexpr (FASTDIV) {
@@ -741,6 +746,7 @@ struct SolveArgs {
     double *cost;          // [N]
     double *path_dist;     // [N][H] or null
     int *crash;            // [N] or null
+    double *action_cost;   // [N][2] or null: (cell of the first step as a double, -1 if the path has none; cost) -- the fused row the multi-GPU gather moves
     double *s_sequence;    // grid mode: [H]
 };
 
@@ -1222,8 +1228,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                                 // 0.05 cell even for a radius of 5000 cells.  Cells outside [m - rad, m + rad] cost more than the inflated slack;
                                 // 0.01 cell covers the rounding of the lattice coordinates and of this interval.
                                 const double rad = (double)(__builtin_amdgcn_sqrtf((float)(room * nk.invK)) * 1.00001f);
-                                const int nlo_ = i + (int)ceil(__builtin_fma(m_ - rad, r_delta, -0.01));
-                                const int nhi_ = i + (int)floor(__builtin_fma(m_ + rad, r_delta, 0.01)) + 1;
+                                // (clamped before the conversion: an over-sized or non-finite radius -- a huge bound against a tiny K -- must degenerate to
+                                // "no filtering", not to a saturated conversion that wraps i + INT_MAX + 1 negative and drops every candidate)
+                                const int nlo_ = i + (int)cell_lo(ceil(__builtin_fma(m_ - rad, r_delta, -0.01)));
+                                const int nhi_ = i + (int)cell_hi(floor(__builtin_fma(m_ + rad, r_delta, 0.01))) + 1;
                                 if (nlo_ > lo || nhi_ < hi) cut_l = true;
                                 lo = nlo_ > lo ? nlo_ : lo; hi = nhi_ < hi ? nhi_ : hi;
                             }
@@ -1240,8 +1248,8 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             q_smin = sv + m_;
                             q_base = Cf + (float)emin;
                             // (no spare cells beyond the interval: the band is a heuristic)
-                            const int nlo_ = i + (int)ceil((m_ - rad_b) * r_delta);
-                            const int nhi_ = i + (int)floor((m_ + rad_b) * r_delta) + 1;
+                            const int nlo_ = i + (int)cell_lo(ceil((m_ - rad_b) * r_delta));
+                            const int nhi_ = i + (int)cell_hi(floor((m_ + rad_b) * r_delta)) + 1;
                             // never drop everything: a source whose whole window lies off the minimiser keeps its nearest end
                             const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
                             if (a_ < b_) { lo = a_; hi = b_; }
@@ -1628,8 +1636,8 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
                     edge_quad_source(nk, sv - p1, p1 - p2, m_, emin);
                     q_smin = sv + m_;
                     q_base = Cf + (float)emin;
-                    const int nlo_ = i + (int)ceil((m_ - rad) * r_delta);
-                    const int nhi_ = i + (int)floor((m_ + rad) * r_delta) + 1;
+                    const int nlo_ = i + (int)cell_lo(ceil((m_ - rad) * r_delta));
+                    const int nhi_ = i + (int)cell_hi(floor((m_ + rad) * r_delta)) + 1;
                     const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
                     if (a_ < b_) { lo = a_; hi = b_; }
                     else if (nlo_ >= hi) lo = hi - 1;
@@ -1827,8 +1835,8 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
                     edge_quad_source(nk, sv - p1, p1 - p2, m_, emin);
                     q_smin = sv + m_;
                     q_base = Cf + (float)emin;
-                    const int nlo_ = i + (int)ceil((m_ - rad) * r_delta);
-                    const int nhi_ = i + (int)floor((m_ + rad) * r_delta) + 1;
+                    const int nlo_ = i + (int)cell_lo(ceil((m_ - rad) * r_delta));
+                    const int nhi_ = i + (int)cell_hi(floor((m_ + rad) * r_delta)) + 1;
                     const int a_ = nlo_ > lo ? nlo_ : lo, b_ = nhi_ < hi ? nhi_ : hi;
                     if (a_ < b_) { lo = a_; hi = b_; }
                     else if (nlo_ >= hi) lo = hi - 1;
@@ -2093,6 +2101,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             } else {
                 a.path_idx[(size_t)e * H + t] = n;
                 if (a.path_dist) a.path_dist[(size_t)e * H + t] = pd;
+                if (t == 1 && a.action_cost) a.action_cost[(size_t)e * 2] = (double)n;
             }
         }
         const bool any_crash = __ballot(crash_l) != 0ull;
@@ -2100,6 +2109,7 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             if (lane == 0) {
                 a.best_t[e] = best_t;
                 a.cost[e] = __longlong_as_double((long long)best_bits);
+                if (a.action_cost) a.action_cost[(size_t)e * 2 + 1] = __longlong_as_double((long long)best_bits);
                 if (a.crash) a.crash[e] = (best_t != H - 1 || any_crash) ? 1 : 0;
             }
         }

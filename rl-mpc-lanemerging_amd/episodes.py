@@ -75,12 +75,19 @@ class EpisodeRunner:
         from . import combined
         torch, ctx, n, kmax = self.torch, self.ctx, self.n, self.kmax
         ctx.sim_view(self.cfg, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr(),
-                     self.d_oa.data_ptr() if self.controller == "combined" else 0)
+                     self.d_oa.data_ptr() if self.controller != "st" else 0)
         if self.controller == "st":
             ctx.st_control_batch_device(self.params, self.tick_length, n, kmax, self.d_ego5.data_ptr(), self.d_k.data_ptr(), self.d_ox.data_ptr(), self.d_ov.data_ptr(),
                                         self.d_path.data_ptr(), self.d_bt.data_ptr(), self.d_cost.data_ptr(), self.d_speed.data_ptr(), self.d_fine.data_ptr(),
                                         self.d_fine_len.data_ptr(), 0)
             cmd = self.d_speed
+        elif self.controller == "policy":
+            # the policy alone (TASK EVALUATE_DDPG: RLAgent.do_control = control.set_ego_jerk(get_control(state)), dqn.py:95-96, control.py:160-178)
+            S = Settings
+            ego4 = self.d_ego5[:, :4].contiguous()
+            jerk = self.policy(1, ego4, self.d_k, self.d_ox, self.d_ov, self.d_oa).to(torch.float64)
+            acc = torch.clamp(ego4[:, 3] + jerk * self.tick_length, S.MAX_NEGATIVE_ACCELERATION, S.MAX_POSITIVE_ACCELERATION)
+            cmd = torch.clamp(ego4[:, 2] + acc * self.tick_length, 0.0, float(S.MAX_SPEED)).contiguous()
         else:
             d = combined.decide_batch_device(ctx, self.params, self.ccfg, self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.policy, self.last_rl, d_oa=self.d_oa)
             cmd = d["speed"]
@@ -123,7 +130,7 @@ def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max
     (combined controller only).
 
     controller: "st" = ``st.do_st_control`` every tick (TASK "ST"); "combined" = ``do_combined_control`` with ``policy``
-    (see ``combined.decide_batch_device``)."""
+    (see ``combined.decide_batch_device``); "policy" = the policy's jerk alone every tick (TASK EVALUATE_DDPG)."""
     r = EpisodeRunner(n, seed, controller, policy, ctx, kmax, max_episode_length)
     limit = r.cfg.max_ticks + 1 if max_ticks is None else min(int(max_ticks), r.cfg.max_ticks + 1)
     for tick in range(limit):

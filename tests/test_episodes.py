@@ -4,9 +4,9 @@ compares the per-episode means of the reference's pure-ST evaluation at its thre
 rows st_low / st_medium / st_default, 4000-10000 SUMO episodes each) with 1024 episodes of this world, with tolerances set just above
 what is measured (time to merge +0.9 ... +2.4 %, mean speed -1.4 ... -2.9 %, mean |jerk| -1 ... -2 % in dense and
 medium traffic): every episode merges, at most 0.5 % crash (reference: none), time to merge and mean speed within 5 %, maximum speed
-within 3 %, closest distance within 6 %, mean |jerk| within 10 % at 1.8 s and 1.2 s headway.  Known gap, kept visible instead of hidden
-in a loose bound: mean |jerk| at 2.4 s headway is +20 % (1.29 against 1.07) and is asserted to lie in that band -- a move in either
-direction fails the test and has to be looked at."""
+within 3 %, closest distance within 6 %, mean |jerk| within 10 % at 1.8 s and 1.2 s headway.  Known gap, kept visible: mean |jerk| at
+2.4 s headway is +20 % (1.29 against 1.07); the test prints the measured deviation and fails if it grows beyond +30 % (an improvement
+passes)."""
 import numpy as np
 import pytest
 
@@ -34,8 +34,9 @@ def test_st_episodes_match_the_reference_statistically(interval, gpu_ctx, restor
     assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.05 * ref["mean_speed"]
     assert abs(s["max_speed"] - ref["max_speed"]) <= 0.03 * ref["max_speed"]
     jerk_dev = s["mean_abs_jerk"] / ref["mean_abs_jerk"] - 1.0
+    print("headway %.1f s: mean |jerk| %.3f, %+.1f %% against the reference's %.3f" % (interval, s["mean_abs_jerk"], 100 * jerk_dev, ref["mean_abs_jerk"]))
     if interval == 2.4:
-        assert 0.10 <= jerk_dev <= 0.30, jerk_dev                  # the known gap in light traffic (+20 %): neither worse nor silently "fixed"
+        assert -0.10 <= jerk_dev <= 0.30, jerk_dev                 # the known gap in light traffic (+20 %): may close, must not grow
     else:
         assert abs(jerk_dev) <= 0.10, jerk_dev
     assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.06 * ref["closest_distance"]

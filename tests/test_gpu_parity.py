@@ -328,8 +328,8 @@ def test_edge_cases(gpu_ctx, restore_settings):
 
 
 def test_full_size_batch_properties(gpu_ctx, restore_settings):
-    """BASELINE-size batch (4096 episodes, H=40, S=7201, fan-out 21): size-independent properties.
-    (The bit-for-bit check of all 4096 against the oracle is part of bench.py's cpu_baseline leg.)"""
+    """BASELINE-size batch (4096 episodes, H=40, S=7201, fan-out 21): size-independent properties, then ALL 4096 episodes bit for bit against
+    the oracle's layered DP (paths, deepest layer, cost bits, crash verdict) and every 16th against its literal heap Dijkstra."""
     import rl_mpc_lanemerging_amd as pkg
     from rl_mpc_lanemerging_amd import _capi, st, synth
     from oracle import st_oracle as orc
@@ -364,11 +364,51 @@ def test_full_size_batch_properties(gpu_ctx, restore_settings):
     assert (d[valid[:, 1:]] <= vmax_cells).all()               # speed limit
     assert np.isfinite(r1["cost"]).all() and (r1["cost"][bt > 0] > 0).all()
     assert ((bt < H - 1) <= (r1["crash"] == 1)).all()          # a truncated path is always reported as a guaranteed crash
-    # spot-check 64 episodes bit-for-bit against the literal heap restatement
+    # every episode against the oracle (layered DP, ~2 s on the box's 16 usable cores); every 16th against the literal heap restatement
     op = orc.OrcParams.from_dict(p.as_dict())
-    sel = np.arange(0, n, 64)
-    ref = orc.solve_batch(op, ego[sel], kc[sel], ox[sel], ov[sel], solver="heap", nthreads=8)
-    assert np.array_equal(ref["path_idx"], path[sel]) and np.array_equal(ref["cost"], r1["cost"][sel])
+    _assert_batch_equals_oracle(orc, op, ego, kc, ox, ov, r1, heap_every=16)
+
+
+def _assert_batch_equals_oracle(orc, op, ego, kc, ox, ov, res, heap_every):
+    ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=16)
+    for key in ("path_idx", "best_t", "crash"):
+        assert np.array_equal(ref[key], res[key]), key
+    assert np.array_equal(ref["cost"].view(np.uint64), res["cost"].view(np.uint64)), "cost bits"
+    sel = np.arange(0, ego.shape[0], heap_every)
+    heap = orc.solve_batch(op, ego[sel], kc[sel], ox[sel], ov[sel], solver="heap", nthreads=16)
+    assert np.array_equal(heap["path_idx"], res["path_idx"][sel]) and np.array_equal(heap["best_t"], res["best_t"][sel])
+    assert np.array_equal(heap["cost"].view(np.uint64), res["cost"][sel].view(np.uint64)) and np.array_equal(heap["crash"], res["crash"][sel])
+
+
+def test_fused_action_cost_rows_and_one_8192_shard(gpu_ctx, restore_settings):
+    """BASELINE configs[3]'s per-rank shard (8192 of 65536 episodes, H=40): every episode against the oracle, every 16th against the heap; and
+    the fused (action, cost) rows the solver writes for the multi-GPU gather (stmpc_solve_batch_device_ac) equal (path_idx[:, 1], cost)."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, synth
+    from oracle import st_oracle as orc
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
+    p = _capi.Params.from_settings(pkg.Settings)
+    H = _capi.num_t(p)
+    n = 8192
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=8, seed=2000)            # rank 0's shard of bench.py's config4 leg
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = lambda a: torch.as_tensor(a, device=dev)
+    d_ego, d_k, d_ox, d_ov = t(ego), t(kc), t(ox), t(ov)
+    d_path = torch.empty((n, H), dtype=torch.int32, device=dev); d_bt = torch.empty(n, dtype=torch.int32, device=dev)
+    d_cost = torch.empty(n, dtype=torch.float64, device=dev); d_crash = torch.empty(n, dtype=torch.int32, device=dev)
+    d_ac = torch.full((n, 2), float("nan"), dtype=torch.float64, device=dev)
+    gpu_ctx.solve_batch_device(p, n, 8, d_ego.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), d_path.data_ptr(), d_bt.data_ptr(),
+                               d_cost.data_ptr(), 0, d_crash.data_ptr(), torch.cuda.current_stream().cuda_stream, d_ac.data_ptr())
+    torch.cuda.synchronize()
+    stats = gpu_ctx.stats()
+    assert stats["resume_refused"] in (0, 1)
+    assert torch.equal(d_ac[:, 0].to(torch.int32), d_path[:, 1]) and torch.equal(d_ac[:, 1], d_cost)
+    assert bool((d_ac[:, 0] == d_ac[:, 0].round()).all())
+    res = {"path_idx": d_path.cpu().numpy(), "best_t": d_bt.cpu().numpy(), "cost": d_cost.cpu().numpy(), "crash": d_crash.cpu().numpy()}
+    op = orc.OrcParams.from_dict(p.as_dict())
+    _assert_batch_equals_oracle(orc, op, ego, kc, ox, ov, res, heap_every=16)
 
 
 def _random_overrides(rng):
