@@ -1,5 +1,5 @@
 """One H40/A21 batch with the timing build: per-episode stamps + the pre-pass bound (slot 13) -> gpurun_out/times_ub.bin, and the
-solver's cost / best_t -> gpurun_out/times_ub_cost.npy, times_ub_bt.npy (inputs of oracle/analysis/badbound*.py)."""
+solver's cost / best_t -> gpurun_out/times_ub_cost.npy, times_ub_bt.npy (inputs of oracle/analysis/badbound.py)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
