@@ -734,6 +734,7 @@ struct SolveArgs {
     int prio_mode;         // (experiment: which estimate prio_thr is compared with)
     int prio_thr;          // first window: an overflowing search with more than this much left (layers x nodes) joins the front class of the next queue; 0 = off
     int retry_move;        // first window: after this many failed exact passes of an episode the next one runs in the second window (0 = never)
+    double bound_infl;     // a bounding pass's single-precision total times this is the bound (its rounding alone needs 1.00002; see stmpc.hip)
     double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
     unsigned *cu_tab;      // null = off
     int retire_from;
@@ -1514,7 +1515,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     if constexpr (MODE == PASS_BOUND) {
         // the bound: the path's cost as accumulated in single precision (error below 1e-5 relative: <= 2^-23 per operation, ~4 operations
         // per layer, H layers), inflated beyond that -- any value is safe, the exact pass re-checks
-        const double ub = (double)__uint_as_float((unsigned)(out.best_bits >> 32)) * 1.00002;
+        const double ub = (double)__uint_as_float((unsigned)(out.best_bits >> 32)) * a.bound_infl;
         out.best_bits = (u64)__double_as_longlong(ub);
     }
     out.pruned = (sh.flags & 1) != 0;
@@ -1680,7 +1681,7 @@ __device__ __forceinline__ bool tube_pass(const SolveArgs &a, const Ep &ep, WgSh
     M::barrier();
     out.nodes = sh.nlist;
     out.best_t = complete ? H - 1 : 0;
-    if (complete) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * 1.00002);
+    if (complete) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * a.bound_infl);
     M::barrier();                        // (sh.nlist, the arrays: free for the next user)
     return complete;
 }
@@ -1878,7 +1879,7 @@ __device__ __forceinline__ int band_pass(const SolveArgs &a, const Ep &ep, WgSha
     }
     out.nodes = total_nodes;
     out.best_t = rc == 0 ? H - 1 : 0;
-    if (rc == 0) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * 1.00002);
+    if (rc == 0) out.best_bits = (u64)__double_as_longlong((double)__uint_as_float((unsigned)(lmin >> 32)) * a.bound_infl);
     M::barrier();                        // the arrays are free for the next user
     return rc;
 }
