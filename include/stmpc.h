@@ -17,6 +17,7 @@
  *   stmpc_rollout_step_device / stmpc_combined_decide_device <- dqn.RLAgent.do_combined_control  dqn.py:117-200 (the policy
  *                                network stays the caller's; everything around it runs here)
  *   stmpc_policy_features_device <- dqn.get_state_vector_from_base_state  dqn.py:389-446 (+ the float32 cast and TimeFeature input of ddpg.py:41,84)
+ *   stmpc_actor_eval_device   <- DDPGAgent.get_control                ddpg.py:83-87 (state vector + the pretrained policy network, one launch)
  *   stmpc_ego_s               <- control.get_ego_s                   control.py:373-380
  *   stmpc_num_s / stmpc_num_t <- the np.arange sizes at st.py:31-32
  *
@@ -362,6 +363,24 @@ int stmpc_policy_features_len(const stmpc_policy_features_cfg *cfg);
 int stmpc_policy_features_device(stmpc_ctx *ctx, const stmpc_policy_features_cfg *cfg, int N, int Kmax, int step, const double *d_cur_ego4,
                                  const int32_t *d_k_count, const double *d_cur_other_x, const double *d_cur_other_v, const double *d_cur_other_a,
                                  int32_t *d_evals, float *d_feat, int feat_stride, void *stream);
+
+/*
+ * The policy network itself on the device (optional -- a caller may keep the network in its own framework and only take the input vectors from
+ * stmpc_policy_features_device): the reference's DDPGAgent.get_control (ddpg.py:83-87) for N states in ONE launch = the state vector above ->
+ * Linear(n_in, h1) -> ReLU -> Linear(h1, h2) -> ReLU -> Linear(h2, 1) -> tanh * tanh_scale + tanh_mean (the `all` library's fc_deterministic_policy
+ * behind ddpg.py:29-41; 21 -> 400 -> 300 -> 1, scale 5, mean 0 for the reference's pretrained_models/), float32 throughout like the reference's
+ * torch modules, hidden layers on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 fused multiply-adds in a fixed order).
+ * stmpc_actor_create takes HOST pointers to row-major weights as torch stores them (w0 [h1][n_in], w1 [h2][h1], w2 [h2], biases) and packs
+ * them for the kernel; n_in <= 32, h1, h2 <= 1024 and small enough for one workgroup's LDS.  stmpc_actor_eval_device: arguments as
+ * stmpc_policy_features_device (d_feat may be NULL) plus d_jerk [N] fp64, the proposed jerk per state.
+ */
+typedef struct stmpc_actor stmpc_actor;
+int  stmpc_actor_create(stmpc_ctx *ctx, int n_in, int h1, int h2, const float *w0, const float *b0, const float *w1, const float *b1,
+                        const float *w2, const float *b2, double tanh_scale, double tanh_mean, stmpc_actor **out);
+void stmpc_actor_destroy(stmpc_actor *actor);
+int  stmpc_actor_eval_device(stmpc_ctx *ctx, const stmpc_actor *actor, const stmpc_policy_features_cfg *cfg, int N, int Kmax, int step,
+                             const double *d_cur_ego4, const int32_t *d_k_count, const double *d_cur_other_x, const double *d_cur_other_v,
+                             const double *d_cur_other_a, int32_t *d_evals, float *d_feat, int feat_stride, double *d_jerk, void *stream);
 
 /* Host copies of the context's rollout bookkeeping and intermediate results (synchronises; any pointer may be NULL):
  * live, hist_len, crash_pred, have_test [N]; sel_speed [N]; rollout_s [N][rollout_length + 1]; test_ego4 [N][4], test_ox / test_ov [N][Kmax];

@@ -107,6 +107,7 @@ EXPORTS = (
     "stmpc_sim_init_device", "stmpc_sim_view_device", "stmpc_sim_step_device", "stmpc_sim_read", "stmpc_fastdiv2_check",
     "stmpc_abi_version", "stmpc_check_error", "stmpc_predict_batch_acc", "stmpc_sim_status_device",
     "stmpc_policy_features_device", "stmpc_policy_features_len", "stmpc_combined_counts", "stmpc_solve_batch_device_ac",
+    "stmpc_actor_create", "stmpc_actor_destroy", "stmpc_actor_eval_device",
 )
 ABI_VERSION = 4     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
@@ -174,6 +175,11 @@ def load():
     sp = C.POINTER(SimCfg)
     lib.stmpc_policy_features_len.argtypes = [C.POINTER(FeaturesCfg)]
     lib.stmpc_policy_features_device.argtypes = [vp, C.POINTER(FeaturesCfg), C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int, vp]
+    fp = C.POINTER(C.c_float)
+    lib.stmpc_actor_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, C.c_double, C.c_double, C.POINTER(vp)]
+    lib.stmpc_actor_destroy.argtypes = [vp]
+    lib.stmpc_actor_destroy.restype = None
+    lib.stmpc_actor_eval_device.argtypes = [vp, vp, C.POINTER(FeaturesCfg), C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int, vp, vp]
     lib.stmpc_combined_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
     lib.stmpc_sim_init_device.argtypes = [vp, sp, C.c_int, vp]
     lib.stmpc_sim_view_device.argtypes = [vp, sp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -441,6 +447,25 @@ class Context:
         """The policy's float32 input vectors (dqn.get_state_vector_from_base_state + TimeFeature) into ``d_feat`` [N][feat_stride]."""
         self._chk(self._lib.stmpc_policy_features_device(self._h, C.byref(fcfg), int(N), int(Kmax), int(step), d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
                                                          d_cur_oa, d_evals, d_feat, int(feat_stride), stream))
+
+    def actor_create(self, w):
+        """Pack and upload a policy network (dict of numpy float32 arrays w0, b0, w1, b1, w2, b2 as torch stores them + tanh_scale, tanh_mean);
+        returns an opaque handle for ``actor_eval_device`` / ``actor_destroy``."""
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        w0, b0, w1, b1, w2, b2 = f32(w["w0"]), f32(w["b0"]), f32(w["w1"]), f32(w["b1"]), f32(w["w2"]).reshape(-1), f32(w["b2"]).reshape(-1)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        h = C.c_void_p()
+        self._chk(self._lib.stmpc_actor_create(self._h, int(w0.shape[1]), int(w0.shape[0]), int(w1.shape[0]), fp(w0), fp(b0), fp(w1), fp(b1), fp(w2), fp(b2),
+                                               float(w["tanh_scale"]), float(w["tanh_mean"]), C.byref(h)))
+        return h
+
+    def actor_destroy(self, handle):
+        self._lib.stmpc_actor_destroy(handle)
+
+    def actor_eval_device(self, handle, fcfg, N, Kmax, step, d_cur_ego4, d_k, d_cur_ox, d_cur_ov, d_cur_oa, d_evals, d_feat, feat_stride, d_jerk, stream=0):
+        """One launch: state vectors + the packed network -> proposed jerk [N] fp64 (``stmpc_actor_eval_device``)."""
+        self._chk(self._lib.stmpc_actor_eval_device(self._h, handle, C.byref(fcfg), int(N), int(Kmax), int(step), d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
+                                                    d_cur_oa, d_evals, d_feat, int(feat_stride), d_jerk, stream))
 
     def combined_counts(self, reset=False):
         """(decisions taken, controller solves run for them) since the last reset."""

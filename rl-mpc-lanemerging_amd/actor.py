@@ -8,10 +8,14 @@
     action = TimeFeature(GreedyAgent(policy)).eval(state)       ddpg.py:40-41: 21st input = 0.001 x evaluations so far; the network;
                                                                 DeterministicPolicyNetwork: tanh(.) * 5 + 0
 
-Here: the input vectors are built by ``k_policy_features`` (``stmpc_policy_features_device``, one thread per state, float32 out), the
-network -- 21 -> 400 -> ReLU -> 300 -> ReLU -> 1, the tensors of the reference's ``pretrained_models/ddpg_*_extended/policy.pt`` exported
-as data by ``tests/golden/make_actor_weights.py`` -- runs on PyTorch-ROCm (three rocBLAS GEMMs) in float32 like the reference's, and the
-squash is ``tanh * tanh_scale + tanh_mean``.
+Here the network is 21 -> 400 -> ReLU -> 300 -> ReLU -> 1 with the tensors of the reference's ``pretrained_models/ddpg_*_extended/policy.pt``
+(exported as data by ``tests/golden/make_actor_weights.py``), float32 like the reference's, squash ``tanh * tanh_scale + tanh_mean``, in
+two interchangeable engines:
+
+* ``engine="hip"`` (default): ONE launch per evaluation, ``k_actor_eval`` (``stmpc_actor_eval_device``): state vector, both hidden layers on
+  the matrix cores (``v_mfma_f32_16x16x4_f32``, weights pre-packed in lane order), output layer and squash; activations stay in LDS;
+* ``engine="torch"``: the input vectors from ``k_policy_features`` (``stmpc_policy_features_device``), the network on PyTorch-ROCm (three
+  rocBLAS GEMMs + elementwise kernels) -- BASELINE configs[2]'s literal wording, and the float32 reference the fused kernel is tested against.
 
 Parity: the 20 state-vector entries and the network's weights are the reference's own (pinned by ``golden_combined_real.npz``); the
 float32 cast and the TimeFeature input restate ``autonomous-learning-library`` 0.5.3 (requirements.txt:10), which is absent from the
@@ -88,15 +92,21 @@ class DDPGActor:
 
     Holds the per-episode evaluation counters of the reference's TimeFeature wrapper (``evals``, int32 [N] on the device;
     ``reset(mask)`` zeroes them where an episode ends, as ``end_episode_callback`` does, ddpg.py:89-90).
-    ``dtype``: torch.float32 evaluates the network as the reference does; torch.float64 is offered for sensitivity measurements.
-    ``time_feature=False`` feeds 0 as the 21st input (the sensitivity test's other arm)."""
+    ``engine``: "hip" (one fused launch) or "torch" (see the module text).  ``dtype`` (torch engine only): torch.float32 evaluates the network
+    as the reference does; torch.float64 is offered for sensitivity measurements.  ``time_feature=False`` feeds 0 as the 21st input (the
+    sensitivity test's other arm; the evaluation counters still run)."""
 
-    def __init__(self, name, n, ctx, S, device=None, dtype=None, time_feature=True):
+    def __init__(self, name, n, ctx, S, device=None, dtype=None, time_feature=True, engine="hip"):
         import torch
         self.torch = torch
         self.name = name
         self.ctx = ctx
         self.n = int(n)
+        if engine not in ("hip", "torch"):
+            raise ValueError("engine must be 'hip' or 'torch'")
+        if dtype is not None and dtype != torch.float32 and engine == "hip":
+            engine = "torch"                      # the fused kernel is float32 only
+        self.engine = engine
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype or torch.float32
         w = load_weights(name)
@@ -106,13 +116,24 @@ class DDPGActor:
         self.w2t, self.b2 = t(w["w2"]).t().contiguous(), t(w["b2"])
         self.scale, self.mean = w["tanh_scale"], w["tanh_mean"]
         self.fcfg = _capi.FeaturesCfg.from_settings(S, time_feature=True)
-        self.count_time = bool(time_feature)
+        if not time_feature:
+            self.fcfg.time_scale = 0.0            # the input reads 0 x evaluations
         self.flen = (self.fcfg.cars_ahead + self.fcfg.cars_behind) * (4 if self.fcfg.use_acceleration else 3) + 5
         if self.flen != self.w0t.shape[0]:
             raise ValueError("the actor takes %d inputs, the state vector of these settings has %d" % (self.w0t.shape[0], self.flen))
         self.evals = torch.zeros(self.n, dtype=torch.int32, device=dev)
         self.feat = torch.empty(self.n, self.flen, dtype=torch.float32, device=dev)
-        self.last_features = None
+        self.jerk = torch.empty(self.n, dtype=torch.float64, device=dev)
+        self.keep_features = False                # hip engine: also write the input vectors to ``self.feat`` (tests)
+        self.handle = ctx.actor_create(w) if engine == "hip" else None
+
+    def __del__(self):
+        if getattr(self, "handle", None) is not None:
+            try:
+                self.ctx.actor_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
 
     def reset(self, mask=None):
         if mask is None:
@@ -125,8 +146,6 @@ class DDPGActor:
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         self.ctx.policy_features_device(self.fcfg, self.n, cur_ox.shape[1], step, cur_ego4.data_ptr(), k.data_ptr(), cur_ox.data_ptr(), cur_ov.data_ptr(),
                                         cur_oa.data_ptr() if cur_oa is not None else 0, self.evals.data_ptr(), self.feat.data_ptr(), self.flen, stream)
-        if not self.count_time:
-            self.feat[:, self.flen - 1] = 0.0
         return self.feat
 
     def forward(self, feat):
@@ -137,6 +156,12 @@ class DDPGActor:
         return torch.tanh(torch.addmm(self.b2, h, self.w2t)).squeeze(1) * self.scale + self.mean
 
     def __call__(self, step, cur_ego4, k, cur_ox, cur_ov, cur_oa):
+        if self.engine == "hip":
+            stream = self.torch.cuda.current_stream().cuda_stream
+            self.ctx.actor_eval_device(self.handle, self.fcfg, self.n, cur_ox.shape[1], step, cur_ego4.data_ptr(), k.data_ptr(), cur_ox.data_ptr(),
+                                       cur_ov.data_ptr(), cur_oa.data_ptr() if cur_oa is not None else 0, self.evals.data_ptr(),
+                                       self.feat.data_ptr() if self.keep_features else 0, self.flen, self.jerk.data_ptr(), stream)
+            return self.jerk
         with self.torch.no_grad():
             feat = self.features(step, cur_ego4, k, cur_ox, cur_ov, cur_oa)
             return self.forward(feat).to(self.torch.float64)

@@ -52,28 +52,37 @@ def run(args, rank, world, dev, dist):
     d_ox, d_ov = torch.as_tensor(ox, device=dev), torch.as_tensor(ov, device=dev)
     d_evals0 = torch.as_tensor(evals0, device=dev)
     from rl_mpc_lanemerging_amd import actor as actor_mod
-    policy = actor_mod.DDPGActor(COMBINED_MEDIUM_1_ACTOR, n, ctx, S, dev)
 
-    def tick():
-        policy.evals.copy_(d_evals0)          # every timed tick is the same tick of the same episodes
-        return combined.decide_batch_device(ctx, params, cfg, d_ego, d_k, d_ox, d_ov, policy, None, torch.cuda.current_stream().cuda_stream)
+    def timed(engine):
+        policy = actor_mod.DDPGActor(COMBINED_MEDIUM_1_ACTOR, n, ctx, S, dev, engine=engine)
 
-    for _ in range(args.warmup):
-        d = tick()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d = tick()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def tick():
+            policy.evals.copy_(d_evals0)          # every timed tick is the same tick of the same episodes
+            return combined.decide_batch_device(ctx, params, cfg, d_ego, d_k, d_ox, d_ov, policy, None, torch.cuda.current_stream().cuda_stream)
+
+        for _ in range(args.warmup):
+            d_ = tick()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d_ = tick()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, d_
+
+    # BASELINE configs[2] words the actor as "on PyTorch-ROCm": timed that way too, next to the fused kernel the package uses by default
+    elapsed_torch, d_torch = timed("torch")
+    ctx.combined_counts(reset=True)
+    elapsed, d = timed("hip")
+    same_decisions = int((d["reason"] != d_torch["reason"]).sum().item())
     reason = d["reason"].cpu().numpy()
     decisions, control_solves = ctx.combined_counts()
     out = {"metric": "combined RL+MPC controller ticks/sec (configs/combined_medium_1.json, pretrained ddpg_medium1 actor)",
@@ -81,10 +90,13 @@ def run(args, rank, world, dev, dist):
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": "N=%d states/GPU, one tick of dqn.RLAgent.do_combined_control: %d-step policy rollout (pretrained ddpg_medium1 actor, "
-                                  "21-400-300-1, fp32 on PyTorch-ROCm, inputs from k_policy_features), feasibility probe solve, controller solve (H=%d, S=%d) + QP "
+                                  "21-400-300-1, fp32: state vector + network in one fused MFMA launch, k_actor_eval), feasibility probe solve, controller solve (H=%d, S=%d) + QP "
                                   "re-sampling for the states whose decision hands control over, decision"
                                   % (n, max(int(S.ROLLOUT_LENGTH), 1), _capi.num_t(params), _capi.num_s(params, 0.0)),
                       "episodes_per_gpu": n, "actor": COMBINED_MEDIUM_1_ACTOR, "controller_solves_per_decision": control_solves / max(decisions, 1)},
+           "actor_on_pytorch_rocm": {"value": n * world * args.steps / elapsed_torch, "unit": "ticks/s", "ms_per_step": elapsed_torch / args.steps * 1e3,
+                                     "note": "same tick with the network as three rocBLAS GEMMs + elementwise kernels on PyTorch-ROCm (inputs from k_policy_features)",
+                                     "decisions_that_differ_from_the_fused_kernel": same_decisions},
            "decisions": {"policy_kept": int((reason == 0).sum()), "crash_predicted": int((reason == 1).sum()), "too_fast": int((reason == 2).sum()),
                          "probe_rejected": int((reason == 3).sum()), "st_better": int((reason == 4).sum())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -5,6 +5,7 @@
 #include "stmpc_ff_kernels.hpp"
 #include "stmpc_cc_kernels.hpp"
 #include "stmpc_nj_kernels.hpp"
+#include "stmpc_actor_kernels.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -1506,6 +1507,98 @@ int stmpc_policy_features_device(stmpc_ctx *c, const stmpc_policy_features_cfg *
 int stmpc_policy_features_len(const stmpc_policy_features_cfg *f) {
     if (!f) return 0;
     return (f->cars_ahead + f->cars_behind) * (f->use_acceleration ? 4 : 3) + 4 + (f->time_feature ? 1 : 0);
+}
+
+// ---- the policy network itself (optional: the caller may keep it in its own framework and only use stmpc_policy_features_device) ----
+struct stmpc_actor {
+    int device = 0;
+    DevBuf p0, b0, p1, b1, w2;
+    ActorDev dev{};
+    size_t lds = 0;
+};
+
+namespace {
+// [column tile][k block][lane = j + 16 kk][4]: W[n0 + j][k0 + 4 kk + s], zero outside [rows) x [cols)
+std::vector<float> pack_layer(const float *W, int rows, int cols, int rows_p, int cols_p) {
+    std::vector<float> out((size_t)rows_p * cols_p, 0.f);
+    const int kblocks = cols_p / 16;
+    for (int nt = 0; nt < rows_p / 16; ++nt)
+        for (int kb = 0; kb < kblocks; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nt * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4) + q;
+                    if (n < rows && k < cols) out[(((size_t)nt * kblocks + kb) * 64 + lane) * 4 + q] = W[(size_t)n * cols + k];
+                }
+    return out;
+}
+int upload(DevBuf &b, const std::vector<float> &v) {
+    int rc = b.ensure(v.size() * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(b.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return STMPC_OK;
+}
+}  // namespace
+
+int stmpc_actor_create(stmpc_ctx *c, int n_in, int h1, int h2, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                       const float *b2, double tanh_scale, double tanh_mean, stmpc_actor **out) {
+    if (!c || !out) return fail(STMPC_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (!w0 || !b0 || !w1 || !b1 || !w2 || !b2) return fail(STMPC_EINVAL, "NULL weight pointer");
+    if (n_in < 1 || n_in > AT_KIN || h1 < 1 || h1 > 1024 || h2 < 1 || h2 > 1024) return fail(STMPC_EINVAL, "actor shape out of range (n_in <= 32, hidden widths <= 1024)");
+    HIPCHK(hipSetDevice(c->device));
+    const int h1p = (h1 + 15) & ~15, h2p = (h2 + 15) & ~15;
+    const size_t lds = ((size_t)AT_TM * AT_KIN + (size_t)AT_TM * (h1p + 4) + (size_t)AT_TM * (h2p + 4)) * sizeof(float);
+    if (lds + 1024 > (size_t)c->lds_per_block) return fail(STMPC_EINVAL, "actor too wide for one workgroup's LDS");
+    stmpc_actor *a = new stmpc_actor();
+    a->device = c->device; a->lds = lds;
+    std::vector<float> vb0(h1p, 0.f), vb1(h2p, 0.f), vw2(h2p, 0.f);
+    for (int i = 0; i < h1; ++i) vb0[i] = b0[i];
+    for (int i = 0; i < h2; ++i) { vb1[i] = b1[i]; vw2[i] = w2[i]; }
+    int rc;
+    if ((rc = upload(a->p0, pack_layer(w0, h1, n_in, h1p, AT_KIN))) || (rc = upload(a->b0, vb0)) || (rc = upload(a->p1, pack_layer(w1, h2, h1, h2p, h1p))) ||
+        (rc = upload(a->b1, vb1)) || (rc = upload(a->w2, vw2))) { stmpc_actor_destroy(a); return rc; }
+    a->dev.p0 = a->p0.as<float>(); a->dev.b0 = a->b0.as<float>(); a->dev.p1 = a->p1.as<float>(); a->dev.b1 = a->b1.as<float>(); a->dev.w2 = a->w2.as<float>();
+    a->dev.b2 = b2[0]; a->dev.scale = (float)tanh_scale; a->dev.mean = (float)tanh_mean; a->dev.n_in = n_in; a->dev.h1p = h1p; a->dev.h2p = h2p;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_actor_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    *out = a;
+    return STMPC_OK;
+}
+
+void stmpc_actor_destroy(stmpc_actor *a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    a->p0.release(); a->b0.release(); a->p1.release(); a->b1.release(); a->w2.release();
+    delete a;
+}
+
+int stmpc_actor_eval_device(stmpc_ctx *c, const stmpc_actor *a, const stmpc_policy_features_cfg *f, int N, int Kmax, int step, const double *d_cur_ego4,
+                            const int32_t *d_k, const double *d_cur_ox, const double *d_cur_ov, const double *d_cur_oa, int32_t *d_evals, float *d_feat,
+                            int feat_stride, double *d_jerk, void *stream) {
+    if (!c || !a || !f) return fail(STMPC_EINVAL, "NULL argument");
+    if (a->device != c->device) return fail(STMPC_EINVAL, "actor and context are on different devices");
+    if (N < 0 || Kmax < 0 || Kmax > STMPC_KMAX_LIMIT || step < 1) return fail(STMPC_EINVAL, "N, Kmax or step out of range");
+    if (f->cars_ahead < 0 || f->cars_behind < 0 || f->cars_ahead > STMPC_KMAX_LIMIT || f->cars_behind > STMPC_KMAX_LIMIT) return fail(STMPC_EINVAL, "cars_ahead / cars_behind out of range");
+    if (stmpc_policy_features_len(f) != a->dev.n_in) return fail(STMPC_EINVAL, "the actor's input width is not the length of this state vector");
+    if (d_feat && feat_stride < a->dev.n_in) return fail(STMPC_EINVAL, "feat_stride is shorter than the feature vector");
+    if (f->normalize && (!(f->max_speed > 0) || !(f->sensor_radius > 0))) return fail(STMPC_EINVAL, "max_speed and sensor_radius must be positive");
+    if (N == 0) return STMPC_OK;
+    if (!d_cur_ego4 || !d_k || !d_jerk) return fail(STMPC_EINVAL, "NULL device pointer");
+    if (Kmax > 0 && (!d_cur_ox || !d_cur_ov)) return fail(STMPC_EINVAL, "NULL device pointer (vehicles)");
+    if (f->time_feature && !d_evals) return fail(STMPC_EINVAL, "time_feature needs the evaluation counters");
+    const int *live = nullptr;
+    if (step > 1) {
+        if (c->cc_N != N) return fail(STMPC_EINVAL, "step > 1 without a rollout of this size in the context (stmpc_rollout_step_device)");
+        live = c->cc_live.as<int>();
+    }
+    HIPCHK(hipSetDevice(c->device));
+    FeatCfg fc;
+    fc.max_speed = f->max_speed; fc.sensor_radius = f->sensor_radius; fc.time_scale = (float)f->time_scale;
+    fc.cars_ahead = f->cars_ahead; fc.cars_behind = f->cars_behind; fc.use_accel = f->use_acceleration != 0; fc.use_speed_diff = f->use_speed_difference != 0;
+    fc.normalize = f->normalize != 0; fc.time_feature = f->time_feature != 0;
+    hipLaunchKernelGGL(k_actor_eval, dim3((N + AT_TM - 1) / AT_TM), dim3(256), a->lds, (hipStream_t)stream, fc, a->dev, N, Kmax, d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
+                       d_cur_oa, live, d_evals, d_feat, feat_stride, d_jerk);
+    HIPCHK(hipGetLastError());
+    return STMPC_OK;
 }
 
 int stmpc_combined_counts(stmpc_ctx *c, int64_t *decisions, int64_t *control_solves, int reset) {

@@ -165,16 +165,13 @@ struct FeatCfg {
     float time_scale;                     // TimeFeature.scale (0.001)
     int cars_ahead, cars_behind, use_accel, use_speed_diff, normalize, time_feature;
 };
-__global__ void __launch_bounds__(64) k_policy_features(FeatCfg f, int N, int Kmax, const double *__restrict__ ego4, const int *__restrict__ k_count,
-                                                        const double *__restrict__ ox, const double *__restrict__ ov, const double *__restrict__ oa,
-                                                        const int *__restrict__ live /* null: every state is evaluated */, int *evals, float *feat, int stride) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
+__device__ __forceinline__ void dev_policy_features(const FeatCfg &f, int e, int Kmax, const double *__restrict__ ego4, const int *__restrict__ k_count,
+                                                    const double *__restrict__ ox, const double *__restrict__ ov, const double *__restrict__ oa,
+                                                    const int *__restrict__ live /* null: every state is evaluated */, int *evals, float *row) {
     const double ex = ego4[(size_t)e * 4 + 0], ey = ego4[(size_t)e * 4 + 1], ev = ego4[(size_t)e * 4 + 2], ea = ego4[(size_t)e * 4 + 3];
     int k = k_count[e];
     k = k < 0 ? 0 : (k > Kmax ? Kmax : k);
     const int tw = f.use_accel ? 4 : 3;
-    float *row = feat + (size_t)e * stride;
     const int nveh = (f.cars_ahead + f.cars_behind) * tw;
     for (int q = 0; q < nveh; ++q) row[q] = 0.0f;                              // buffer tuples (dqn.py:418-425)
     const double *xs = ox + (size_t)e * Kmax, *vs = ov + (size_t)e * Kmax, *as = oa ? oa + (size_t)e * Kmax : nullptr;
@@ -201,6 +198,13 @@ __global__ void __launch_bounds__(64) k_policy_features(FeatCfg f, int N, int Km
         t[4] = f.time_scale * (float)n;                                       // scale * timestep, single precision as torch evaluates it
         if (!live || live[e]) evals[e] = n + 1;                               // only the states whose rollout goes on ask the policy again (dqn.py:129-133)
     }
+}
+__global__ void __launch_bounds__(64) k_policy_features(FeatCfg f, int N, int Kmax, const double *__restrict__ ego4, const int *__restrict__ k_count,
+                                                        const double *__restrict__ ox, const double *__restrict__ ov, const double *__restrict__ oa,
+                                                        const int *__restrict__ live, int *evals, float *feat, int stride) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    dev_policy_features(f, e, Kmax, ego4, k_count, ox, ov, oa, live, evals, feat + (size_t)e * stride);
 }
 
 // Ordered list of the states whose decision needs st.do_st_control(start_state) (dqn.py:144-155; every branch but the

@@ -160,9 +160,9 @@ def test_gpu_features_and_decisions_with_recorded_jerks(gpu_ctx, restore_setting
 
 @pytest.mark.gpu
 def test_gpu_actor_network_and_its_unpinned_inputs(gpu_ctx, restore_settings):
-    """GPU, floating-point part: the network evaluated on the device (float32 GEMMs on PyTorch-ROCm) against the recorded torch-CPU jerks, and
-    how many of the reference's decisions move (a) with the device's float32 arithmetic, (b) in float64, (c) without the TimeFeature input --
-    the one input that restates an absent library."""
+    """GPU, floating-point part: the network evaluated on the device -- the fused MFMA kernel (k_actor_eval) and the PyTorch-ROCm engine --
+    against the recorded torch-CPU jerks of the reference-side run, and how many of the reference's decisions move (a) with the fused kernel,
+    (b) with torch float32 on the device, (c) in float64, (d) without the TimeFeature input -- the one input that restates an absent library."""
     import torch
     from rl_mpc_lanemerging_amd import _capi, actor, combined
     g, pkg = _golden()
@@ -173,22 +173,147 @@ def test_gpu_actor_network_and_its_unpinned_inputs(gpu_ctx, restore_settings):
     d_ego, d_k, d_ox, d_ov, d_oa = _device_inputs(g, dev)
     n = d_ego.shape[0]
     live = ~np.isnan(g["jerks"])
-    w = actor.load_weights(str(g["actor"]))
-    moved = {}
-    for label, kw in (("fp32", {}), ("fp64", {"dtype": torch.float64}), ("no_time_feature", {"time_feature": False})):
+    moved, first = {}, {}
+    for label, kw in (("hip", dict(engine="hip")), ("torch_fp32", dict(engine="torch")), ("torch_fp64", dict(engine="torch", dtype=torch.float64)),
+                      ("hip_no_time_feature", dict(engine="hip", time_feature=False))):
         pol = actor.DDPGActor(str(g["actor"]), n, gpu_ctx, S, dev, **kw)
         pol.evals.copy_(torch.as_tensor(g["evals0"], device=dev))
-        if label != "no_time_feature":                         # the network alone, on the recorded inputs
+        if pol.engine == "torch" and label != "hip_no_time_feature":       # the network alone, on every recorded input vector
             out = pol.forward(torch.as_tensor(g["vectors"][live], device=dev)).cpu().numpy()
             assert np.abs(out - g["jerks"][live]).max() < 5e-5, label
+        pol.keep_features = True
         d = combined.decide_batch_device(gpu_ctx, params, cfg, d_ego, d_k, d_ox, d_ov, pol, None, torch.cuda.current_stream().cuda_stream, d_oa=d_oa)
         torch.cuda.synchronize()
         gpu_ctx.check_error()
+        assert pol.engine == ("hip" if label.startswith("hip") else "torch")
         reason = d["reason"].cpu().numpy()
         moved[label] = int((reason != g["reason"]).sum())
-        first = d["first_action"].cpu().numpy()
-        if label == "fp32":
-            assert np.abs(first - g["jerks"][:, 0]).max() < 5e-5
+        first[label] = d["first_action"].cpu().numpy()
+        if label in ("hip", "torch_fp32"):
+            assert np.abs(first[label] - g["jerks"][:, 0]).max() < 5e-5, label     # same inputs (bit-exact), float32 sums in another order
+        assert np.array_equal(pol.evals.cpu().numpy() >= g["evals0"] + 1, np.ones(n, bool))
+    assert np.abs(first["hip"] - first["torch_fp32"]).max() < 5e-5
     print("decisions that differ from the reference's (of %d): %s" % (n, moved))
-    assert moved["fp32"] <= n // 200 and moved["fp64"] <= n // 200          # float32 summation order can move a borderline rollout; nothing more
-    assert moved["no_time_feature"] <= n // 10                               # how much hangs on the restated TimeFeature input (reported)
+    for label in ("hip", "torch_fp32", "torch_fp64"):
+        assert moved[label] <= n // 200, (label, moved)                    # float32 summation order can move a borderline rollout; nothing more
+    assert moved["hip_no_time_feature"] <= n // 10                         # how much hangs on the restated TimeFeature input (reported)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_actor_kernel_against_torch_fp32(gpu_ctx, restore_settings):
+    """k_actor_eval alone: for every exported actor, random states (all vehicle counts, N not a multiple of the 32-state tile): its input
+    vectors equal k_policy_features' bit for bit, its jerks equal the PyTorch float32 evaluation of the same network on those inputs within
+    float32 rounding of another summation order, and a re-run gives the same bits; argument checks of the entry."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, actor, synth
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    S = pkg.Settings
+    n, K = 1000 + 7, 8
+    ego, kc, ox, ov = synth.generate_states(n, k=7, kmax=K, seed=12, vary_k=True)
+    rng = np.random.default_rng(13)
+    oa = rng.uniform(-4.0, 2.0, ox.shape)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_ego4, d_k, d_ox, d_ov, d_oa = t(ego[:, :4]), t(kc), t(ox), t(ov), t(oa)
+    evals0 = rng.integers(0, 900, n).astype(np.int32)
+    for name in actor.PRETRAINED:
+        hip = actor.DDPGActor(name, n, gpu_ctx, S, dev, engine="hip")
+        ref = actor.DDPGActor(name, n, gpu_ctx, S, dev, engine="torch")
+        hip.keep_features = True
+        outs = []
+        for _ in range(2):
+            hip.evals.copy_(t(evals0))
+            outs.append(hip(1, d_ego4, d_k, d_ox, d_ov, d_oa).clone())
+        ref.evals.copy_(t(evals0))
+        want = ref(1, d_ego4, d_k, d_ox, d_ov, d_oa)
+        torch.cuda.synchronize()
+        assert torch.equal(hip.feat, ref.feat), name
+        assert torch.equal(outs[0], outs[1]), name
+        assert torch.equal(hip.evals, ref.evals)
+        err = (outs[0] - want).abs().max().item()
+        assert err < 5e-5, (name, err)
+        assert outs[0].abs().max().item() <= 5.0 and outs[0].std().item() > 0.5        # a trained policy: uses its range
+    fc = _capi.FeaturesCfg.from_settings(S, time_feature=False)                          # 20 inputs: not this actor's width
+    with pytest.raises(RuntimeError):
+        gpu_ctx.actor_eval_device(hip.handle, fc, n, K, 1, d_ego4.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), 0, 0, 0, 21, hip.jerk.data_ptr(), 0)
+    with pytest.raises(RuntimeError):
+        gpu_ctx.actor_create(dict(w0=np.zeros((8, 40), np.float32), b0=np.zeros(8, np.float32), w1=np.zeros((8, 8), np.float32), b1=np.zeros(8, np.float32),
+                                  w2=np.zeros((1, 8), np.float32), b2=np.zeros(1, np.float32), tanh_scale=1.0, tanh_mean=0.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [dict(), dict(CARS_AHEAD=1, CARS_BEHIND=3), dict(USE_ACCELERATION_OF_OTHER_CARS=False), dict(USE_SPEED_DIFFERENCE=False),
+                                   dict(NORMALIZE_VECTOR_INPUT=False), dict(CARS_AHEAD=3, CARS_BEHIND=0, USE_ACCELERATION_OF_OTHER_CARS=False, NORMALIZE_VECTOR_INPUT=False)])
+def test_gpu_policy_features_follow_every_flag(flags, gpu_ctx, restore_settings):
+    """k_policy_features against its host twin (the reference's dqn.get_state_vector_from_base_state, statement by statement) for the flag
+    combinations the reference's function has (dqn.py:390-446), incl. vehicle lists that are not sorted and states without vehicles; with and
+    without the TimeFeature input; and the entry's argument checks."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, actor, synth
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(flags)
+    S = pkg.Settings
+    n, K = 300, 8
+    ego, kc, ox, ov = synth.generate_states(n, k=6, kmax=K, seed=9, vary_k=True)
+    rng = np.random.default_rng(10)
+    oa = rng.uniform(-4.0, 2.0, ox.shape)
+    for i in range(0, n, 5):                                   # unsorted lists: the reference takes vehicles in list order, whatever it is
+        kk = int(kc[i])
+        perm = rng.permutation(kk)
+        ox[i, :kk], ov[i, :kk], oa[i, :kk] = ox[i, perm], ov[i, perm], oa[i, perm]
+    evals0 = rng.integers(0, 900, n).astype(np.int32)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_ego4, d_k, d_ox, d_ov, d_oa = t(ego[:, :4]), t(kc), t(ox), t(ov), t(oa)
+    for tf in (True, False):
+        fc = _capi.FeaturesCfg.from_settings(S, time_feature=tf)
+        flen = (fc.cars_ahead + fc.cars_behind) * (4 if fc.use_acceleration else 3) + 4 + (1 if tf else 0)
+        d_evals = t(evals0.copy())
+        feat = torch.full((n, flen + 3), -7.0, dtype=torch.float32, device=dev)
+        gpu_ctx.policy_features_device(fc, n, K, 1, d_ego4.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), d_oa.data_ptr(),
+                                       d_evals.data_ptr() if tf else 0, feat.data_ptr(), flen + 3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = feat.cpu().numpy()
+        assert (got[:, flen:] == -7.0).all()                   # nothing written past the vector
+        for i in range(n):
+            kk = int(kc[i])
+            want = actor.state_vector_host(S, ego[i, :4], ox[i, :kk], ov[i, :kk], oa[i, :kk], int(evals0[i]) if tf else None)
+            assert np.array_equal(got[i, :flen], want), (i, tf)
+        if tf:
+            assert np.array_equal(d_evals.cpu().numpy(), evals0 + 1)
+    fc = _capi.FeaturesCfg.from_settings(S)
+    with pytest.raises(RuntimeError):                          # stride shorter than the vector
+        gpu_ctx.policy_features_device(fc, n, K, 1, d_ego4.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), 0, d_evals.data_ptr(), feat.data_ptr(), 3, 0)
+    with pytest.raises(RuntimeError):                          # the time feature needs its counters
+        gpu_ctx.policy_features_device(fc, n, K, 1, d_ego4.data_ptr(), d_k.data_ptr(), d_ox.data_ptr(), d_ov.data_ptr(), 0, 0, feat.data_ptr(), 64, 0)
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_control_with_no_takeover_at_all(gpu_ctx, restore_settings):
+    """A batch in which no decision calls the controller (a policy that brakes gently far from any vehicle): the sparse path solves nothing,
+    keeps every policy command, and the counters say so."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, combined, combined_bench
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1)
+    S = pkg.Settings
+    n, K = 130, 8
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ego = np.zeros((n, 5)); ego[:, 0] = np.linspace(-220.0, -150.0, n); ego[:, 1] = 20.0; ego[:, 2] = 10.0
+    from rl_mpc_lanemerging_amd import control
+    ego[:, 4] = [control.get_ego_s((x, y)) for x, y in ego[:, :2]]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_ego, d_k, d_ox, d_ov = t(ego), t(np.zeros(n, np.int32)), t(np.zeros((n, K))), t(np.zeros((n, K)))
+    policy = lambda step, e4, k_, x_, v_, a_: torch.full((n,), -0.5, dtype=torch.float64, device=dev)
+    gpu_ctx.combined_counts(reset=True)
+    d = combined.decide_batch_device(gpu_ctx, _capi.Params.from_settings(S), _capi.CombinedCfg.from_settings(S), d_ego, d_k, d_ox, d_ov, policy, None,
+                                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gpu_ctx.check_error()
+    assert int(d["takeover"].sum()) == 0 and int(d["reason"].abs().sum()) == 0
+    want = [combined.get_ego_speed_from_jerk(10.0, 0.0, -0.5)] * n
+    assert np.array_equal(d["speed"].cpu().numpy(), np.array(want))
+    assert gpu_ctx.combined_counts() == (n, 0)
