@@ -28,7 +28,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak
 # counters bench.py cannot regenerate itself (rocprofv3 --pmc passes, scripts/profile_gpu.sh + scripts/profile_summarize.py): the newest
 # round's file that exists.  Each workload entry carries the source hash of the library it was taken from ("csrc_hash"); the bench line says
 # "stale": true wherever it quotes such a counter and the running library was built from other sources.
-MEASURED_CANDIDATES = [os.path.join(REPO, "profiles", r, "measured.json") for r in ("r4", "r3")]
+MEASURED_CANDIDATES = [os.path.join(REPO, "profiles", r, "measured.json") for r in ("r5", "r4", "r3")]
 MEASURED = next((m for m in MEASURED_CANDIDATES if os.path.exists(m)), MEASURED_CANDIDATES[0])
 
 

@@ -39,6 +39,14 @@ class Settings:
     MIN_ALLOWED_DISTANCE = 5
     CRASH_MIN_S = 12
 
+    # The policy's state vector, dqn.get_state_vector_from_base_state (config.py:48-49, 136-139)
+    SENSOR_RADIUS = 125
+    USE_ACCELERATION_OF_OTHER_CARS = True
+    CARS_AHEAD = 2
+    CARS_BEHIND = 2
+    USE_SPEED_DIFFERENCE = True
+    NORMALIZE_VECTOR_INPUT = True
+
     # Prediction (config.py:143)
     MAX_PREDICTED_DECELERATION = -4
 

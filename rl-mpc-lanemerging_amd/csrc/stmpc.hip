@@ -1595,7 +1595,7 @@ int stmpc_actor_eval_device(stmpc_ctx *c, const stmpc_actor *a, const stmpc_poli
     fc.max_speed = f->max_speed; fc.sensor_radius = f->sensor_radius; fc.time_scale = (float)f->time_scale;
     fc.cars_ahead = f->cars_ahead; fc.cars_behind = f->cars_behind; fc.use_accel = f->use_acceleration != 0; fc.use_speed_diff = f->use_speed_difference != 0;
     fc.normalize = f->normalize != 0; fc.time_feature = f->time_feature != 0;
-    hipLaunchKernelGGL(k_actor_eval, dim3((N + AT_TM - 1) / AT_TM), dim3(256), a->lds, (hipStream_t)stream, fc, a->dev, N, Kmax, d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
+    hipLaunchKernelGGL(k_actor_eval, dim3((N + AT_TM - 1) / AT_TM), dim3(AT_THREADS), a->lds, (hipStream_t)stream, fc, a->dev, N, Kmax, d_cur_ego4, d_k, d_cur_ox, d_cur_ov,
                        d_cur_oa, live, d_evals, d_feat, feat_stride, d_jerk);
     HIPCHK(hipGetLastError());
     return STMPC_OK;
