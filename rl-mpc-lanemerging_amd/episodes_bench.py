@@ -13,6 +13,7 @@ import time
 
 import numpy as np
 
+PRE_TICKS = 60          # 12 s of every episode before the timed ticks: the egos are then 80-250 m along the ramp, the first ones merging
 TRAIN_MODERATE_1_ENV = dict(BASE_TRAFFIC_INTERVAL=1.2, OTHER_CAR_SPEED=11.0)       # configs/train_moderate_1.json:7-8 (solver parameters: the shipped defaults)
 
 
@@ -29,6 +30,8 @@ def run(args, rank, world, dev, dist):
     from rl_mpc_lanemerging_amd import actor as actor_mod
     policy = actor_mod.DDPGActor("runs/ddpg_moderate1_extended", n, ctx, S, dev)       # configs/combined_moderate_1.json:4, trained on this traffic (train_moderate_1.json)
     r = episodes.EpisodeRunner(n, seed=5000 + rank, controller="combined", policy=policy, ctx=ctx, kmax=16)
+    for _ in range(PRE_TICKS):          # untimed: bring the environments to mid-episode, where decisions are made (the first ticks on the ramp are idle ones)
+        r.tick()
     for _ in range(args.warmup):
         r.tick()
     if dist is not None:
@@ -55,5 +58,5 @@ def run(args, rank, world, dev, dist):
                                    "probe solve, controller solve (H=%d, S=%d) + QP re-sampling, decision, world step (Krauss traffic %.1f s / %.0f m/s)"
                                    % (n, max(int(S.ROLLOUT_LENGTH), 1), _capi.num_t(r.params), _capi.num_s(r.params, 0.0), S.BASE_TRAFFIC_INTERVAL, S.OTHER_CAR_SPEED),
                        "episodes_per_gpu": n, "note": "BASELINE configs[4] has no counterpart in the reference (its training never calls the solver, SURVEY R7): demo only"},
-            "environments_still_running_at_end": running, "ticks_per_environment": int(r.ticks_done),
+            "environments_still_running_at_end": running, "ticks_per_environment": int(r.ticks_done), "untimed_ticks_before": PRE_TICKS,
             "takeover_share": float(np.nanmean(res["percent_st"]))}
