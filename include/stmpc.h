@@ -35,12 +35,12 @@
  * sets neither rebuild nor wait, and only a fifth set waits for the device (hipDeviceSynchronize) before it replaces the least recently used;
  * and stmpc_combined_decide_device with sparse_control (one integer comes back to the host, see stmpc_combined_cfg).
  * Environment knobs (STMPC_*) are read once, in stmpc_create.
- * Scratch: the wide-lattice solver keeps one back-pointer per lattice cell of the first window and time layer per episode when it may continue
- * an overflowing search in the next window -- one byte (the distance to the predecessor) when no step of the dynamics exceeds 255 cells, else
- * two: N * H * 2048 B = 0.33 GB for 4096 episodes at H = 40, 0.66 GB for 8192, released by stmpc_destroy -- plus a 24 KB checkpoint slot per
- * episode.  The solver takes that only while it is at most a quarter of the device memory that is free at the time (hipMemGetInfo) and at most
- * 8 GB; otherwise, or if the allocation fails, it falls back to per-workgroup storage (restarting instead of continuing overflowing episodes) --
- * results are the same bits.
+ * Scratch: back-pointers (one byte per lattice cell of a window and time layer -- the distance to the predecessor -- when no step of the dynamics
+ * exceeds 255 cells, else two) live per RESIDENT workgroup (84 MB for the first window's 1024 workgroups at H = 40).  Only a search that overflows
+ * the first window keeps anything of its own: an entry of a pool (an eighth of the batch, at least 256 entries; 104 KB each at H = 40: 53 MB for
+ * 4096 episodes) that receives its back-pointer rows and the layer it continues from in the next window.  The pool is taken only while it is at most
+ * a quarter of the device memory that is free at the time (hipMemGetInfo); without it, or beyond its capacity, overflowing searches start over in
+ * the wider window instead of continuing (stmpc_stats: resume_refused, pool_exhausted) -- results are the same bits.
  *
  * Arithmetic contract.  Every operation of the reference's search (st_cy.pyx:34-93) is evaluated as one IEEE-754 fp64 operation in the
  * reference's order; the library is built with FP contraction off.  Two kinds of division are formed without the hardware's division
@@ -125,6 +125,8 @@ typedef struct stmpc_stats {
     int64_t resume_refused;  /* 1: the batch wanted per-episode back-pointers + checkpoints (an overflowing search then continues in the wider window instead of
                                 starting over) and the memory rule turned them down -- they are taken only while they are at most a quarter of the device memory
                                 free at that moment (a process shared with torch / RCCL).  Same results, another schedule; re-priced every 64th call. */
+    int64_t pool_exhausted;  /* overflowing searches that found the checkpoint pool (an eighth of the batch, at least 256 entries) exhausted and started over in the
+                                wider window instead of continuing: same results, more work */
 } stmpc_stats;
 
 /* Totals over the launches issued between stmpc_profile(ctx, 1, ..) and stmpc_profile(ctx, 0, &totals). */

@@ -48,7 +48,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("episodes", C.c_int64), ("fast_path", C.c_int64), ("fallback", C.c_int64), ("hbm_tier", C.c_int64),
                 ("retries", C.c_int64), ("nodes_exact", C.c_int64), ("nodes_bound", C.c_int64),
-                ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double), ("guided", C.c_int64), ("resume_refused", C.c_int64)]
+                ("solve_ms", C.c_double), ("dp_kernel_ms", C.c_double), ("guided", C.c_int64), ("resume_refused", C.c_int64), ("pool_exhausted", C.c_int64)]
 
 
 class CombinedCfg(C.Structure):

@@ -126,7 +126,8 @@ struct stmpc_ctx {
     DevBuf tab_edge, tab_win, tab_nact, tab_nums, counters, lists, ubound, proxy, order, gscratch, bp_tier[STMPC_MAX_TIERS];
     // staging for the host-pointer API
     DevBuf s_ego, s_k, s_ox, s_ov, s_path, s_bt, s_cost, s_pd, s_crash, s_misc0, s_misc1, s_misc2, s_misc3;
-    DevBuf ckpt, resume_t, phase_prof, prio_key;
+    DevBuf ckpt, pool_bp, resume_t, phase_prof, prio_key;
+    int pool_cap_override = 0;     // STMPC_POOL=n: checkpoint pool entries (tests: a tiny pool must only cost speed)
     // combined controller (stmpc_rollout_step_device / stmpc_combined_decide_device): rollout bookkeeping and probe / controller outputs
     DevBuf cc_live, cc_hist_len, cc_crash_pred, cc_have_test, cc_sel, cc_rollout_s, cc_test_ego, cc_test_ox, cc_test_ov, cc_probe_ego, cc_probe_ox, cc_probe_ov,
         cc_path, cc_bt, cc_cost, cc_pcrash, cc_speed, cc_fine, cc_fine_len, cc_err,
@@ -305,6 +306,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_GSH")) { int v = atoi(w); if (v >= 0 && v <= 4) c->gsh_max = v; }
     if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
     if (const char *w = getenv("STMPC_BOUND_INFL")) { double v = atof(w); if (v >= 1.00002 && v <= 2.0) c->bound_infl = v; }
+    if (const char *w = getenv("STMPC_POOL")) { int v = atoi(w); if (v >= 1) c->pool_cap_override = v; }
     if (const char *w = getenv("STMPC_QP_ITERS")) { int v = atoi(w); if (v >= 0 && v <= 1000) c->qp_maxiters = v; }
     // the side stream gets the highest priority: priority levels have their own hardware queues, so its launch
     // cannot end up queued behind the main stream's in a process that owns many streams (torch + RCCL)
@@ -356,7 +358,7 @@ void stmpc_destroy(stmpc_ctx *c) {
     DevBuf *all[] = {&c->guide_cells, &c->sticky, &c->cu_tab, &c->tab_edge, &c->tab_win, &c->tab_nact, &c->tab_nums, &c->counters, &c->lists, &c->ubound, &c->proxy, &c->order, &c->bp_tier[0],
                      &c->bp_tier[1], &c->bp_tier[2], &c->bp_tier[3], &c->bp_tier[4], &c->bp_tier[5], &c->gscratch, &c->s_ego, &c->s_k, &c->s_ox, &c->s_ov, &c->s_path, &c->s_bt, &c->s_cost,
                      &c->s_pd, &c->s_crash, &c->s_misc0, &c->s_misc1, &c->s_misc2, &c->s_misc3,
-                     &c->ckpt, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
+                     &c->ckpt, &c->pool_bp, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
                      &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
                      &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
                      &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed,
@@ -654,45 +656,46 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         tierGrid[nt] = (cleanup_only && c->last_hbm_tier_count <= 16) ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     }
     const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
-    // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt): tier 0 then keeps its back-pointers per
-    // episode (N x H x W0 x 2 B) instead of per resident workgroup
+    // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt, ::pool_bp): a search that cannot build a layer in the first window
+    // saves that layer and the back-pointer rows written so far in an entry of a pool and continues in the second window from there.
     // back-pointers: one byte (distance to the predecessor) when no step of the dynamics exceeds 255 cells, else two (its cell)
     const bool bp_rel8 = ceil(dp.v_max * dp.dt / dp.ds) + 4.0 <= 255.0 && !c->bp16;
     const size_t bp_elem = bp_rel8 ? 1 : sizeof(u16);
-    const size_t bp0_per_episode = (size_t)N * H * tierW[0] * bp_elem;
-    bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1] &&
-                  bp0_per_episode <= ((size_t)8 << 30);      // (compiled for the wide-fan kernels only)
-    if (resume && c->bp_tier[0].cap < bp0_per_episode) {
+    const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
+    // Pool: an eighth of the batch (5 % of the benchmark's searches overflow), at least 256 entries, of H x W0 back-pointers + one saved layer
+    // (104 KB at H = 40): 53 MB for 4096 episodes, 0.85 GB for 65536 -- round 4 kept both for EVERY episode (0.43 GB / 6.9 GB).  A search that
+    // finds the pool exhausted starts over in the wider window (stmpc_stats::pool_exhausted counts them).
+    int pool_cap = c->pool_cap_override > 0 ? c->pool_cap_override : (N / 8 > 256 ? N / 8 : 256);
+    if (pool_cap > N) pool_cap = N;
+    if (pool_cap > (1 << 22)) pool_cap = 1 << 22;            // (the entry number shares a word with the layer)
+    const size_t pool_bytes = (size_t)pool_cap * ((size_t)H * tierW[0] * bp_elem + ckpt_stride);
+    bool resume = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1];      // (compiled for the wide-fan kernels only)
+    if (resume && c->pool_bp.cap + c->ckpt.cap < pool_bytes) {
         // a growing request: only while it is at most a quarter of what the device has free right now (a process shared with torch / RCCL).
-        // A request that was turned down is not priced again (a driver round trip per step) until it changes.
-        // ... but it is priced again every 64th call: memory another tenant held at that moment may be free by now.
-        if (c->resume_refused_for == bp0_per_episode && (++c->resume_refused_calls & 63) != 0) resume = false;
+        // A request that was turned down is priced again every 64th call: memory another tenant held at that moment may be free by now.
+        if (c->resume_refused_for == pool_bytes && (++c->resume_refused_calls & 63) != 0) resume = false;
         else {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-            if (bp0_per_episode + (size_t)N * (16 + (size_t)tierW[0] * 12) > (free_b + c->bp_tier[0].cap) / 4) { resume = false; c->resume_refused_for = bp0_per_episode; }
+            if (pool_bytes > (free_b + c->pool_bp.cap + c->ckpt.cap) / 4) { resume = false; c->resume_refused_for = pool_bytes; }
             else c->resume_refused_for = 0;
         }
     }
     const bool resume_wanted = c->resume && prune_on && !small_fan && !stage_tab && nt >= 2 && tierLds[0] && tierLds[1];
-    const size_t ckpt_stride = 16 + (size_t)tierW[0] * 12;
     // reserved compute units (experiment, STMPC_CU_RESERVE): the first window's persistent grid covers the remaining units only
     const bool reserve_cfg = c->cu_reserve > 0 && prune_on && nt >= 2 && tierLds[0] && tierLds[1] && !c->two_phase;
     if (reserve_cfg) tierGrid[0] = tierGrid[0] / c->num_cu * (c->num_cu - c->cu_reserve);
     for (int k = 0; k < nt; ++k) if (tierGrid[k] > N) tierGrid[k] = N;
     if (resume) {
-        // per-episode back-pointers + checkpoints: if the device cannot spare them (a process shared with torch / RCCL), fall
-        // back to per-workgroup storage -- overflowing episodes then restart in the wider window instead of continuing
-        if (c->bp_tier[0].ensure(bp0_per_episode) || c->ckpt.ensure((size_t)N * ckpt_stride) || c->resume_t.ensure((size_t)N * sizeof(int))) {
+        // the pool: if the device cannot spare it, overflowing searches restart in the wider window instead of continuing
+        if (c->pool_bp.ensure((size_t)pool_cap * H * tierW[0] * bp_elem) || c->ckpt.ensure((size_t)pool_cap * ckpt_stride) || c->resume_t.ensure((size_t)N * sizeof(int))) {
             (void)hipGetLastError();
-            c->bp_tier[0].release(); c->ckpt.release();
+            c->pool_bp.release(); c->ckpt.release();
             resume = false;
         }
     }
-    for (int k = 0; k < nt; ++k) {
-        const size_t need = (k == 0 && resume) ? bp0_per_episode : (size_t)tierGrid[k] * H * tierW[k] * bp_elem;
-        if ((rc = c->bp_tier[k].ensure(need))) return rc;
-    }
+    for (int k = 0; k < nt; ++k)                 // back-pointers of a tier: per resident workgroup
+        if ((rc = c->bp_tier[k].ensure((size_t)tierGrid[k] * H * tierW[k] * bp_elem))) return rc;
     c->last_resume_refused = resume_wanted && !resume;
     int *resume_t = resume ? c->resume_t.as<int>() : nullptr;
     if (need_hbm_tier && (rc = c->gscratch.ensure((size_t)tierGrid[nt - 1] * ((size_t)Wg * STMPC_CELL_BYTES + STMPC_LIST_SLACK + (size_t)Wg * 8)))) return rc;
@@ -790,6 +793,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
     a.phase_prof = c->phase_prof.as<unsigned long long>();
 #endif
     a.ckpt = resume ? c->ckpt.as<unsigned char>() : nullptr; a.ckpt_stride = ckpt_stride; a.resume_t = resume_t;
+    a.pool_bp = resume ? c->pool_bp.as<unsigned char>() : nullptr; a.pool_cap = resume ? pool_cap : 0;
     a.W0 = tierW[0];
     a.maxshift = (int)ceil(dp.v_max * dp.dt / dp.ds) + 2 + 66;     // st_cy.pyx:65-93: v <= v_max; + interval rounding to 64-cell blocks
     a.proxy = c->proxy.as<unsigned>();
@@ -818,7 +822,6 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         a.order = ((phase == 2 || heavy_first) && k == 0) ? c->order.as<int>() : nullptr;
         a.W = tierW[k]; a.PW = tierPW[k]; a.tier = k; a.last_tier = (k == nt - 1);
         a.bp = c->bp_tier[k].as<u16>();
-        a.bp0 = (resume && k >= 1) ? c->bp_tier[0].as<u16>() : nullptr;
         a.gscratch = tierLds[k] ? nullptr : c->gscratch.as<unsigned char>();
         const size_t lds = tierLdsBytes[k];
         const bool std_shape = tierNW[k] == 4 && tierW[k] == 2048 && tierPW[k] == 1024;      // the kernels compiled with these as constants
@@ -945,6 +948,7 @@ int stmpc_get_stats(stmpc_ctx *c, stmpc_stats *out) {
         c->stats.fast_path = c->stats.episodes - cnt[4];
         c->last_hbm_tier_count = c->stats.hbm_tier;
         c->stats.resume_refused = c->last_resume_refused ? 1 : 0;
+        c->stats.pool_exhausted = cnt[STMPC_CNT_POOL_FULL];
         c->stats.retries = cnt[STMPC_CNT_RETRY];
         c->stats.guided = cnt[STMPC_CNT_GUIDED];
         c->stats.nodes_exact = cnt[STMPC_CNT_NODES_EXACT];

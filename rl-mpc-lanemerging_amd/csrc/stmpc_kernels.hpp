@@ -670,6 +670,8 @@ __device__ __forceinline__ double divk(double x, double d, double zh, double zl)
 #define STMPC_CNT_NODES_EXACT 61
 #define STMPC_CNT_NODES_BOUND 60
 #define STMPC_CNT_GUIDED 58      // bounds that came from the guided attempt
+#define STMPC_CNT_POOL 56        // checkpoint pool entries handed out in this step (first window -> second window, see SolveArgs::pool_bp)
+#define STMPC_CNT_POOL_FULL 57   // overflowing searches that found the pool exhausted (they start over in the wider window)
 
 struct SolveArgs {
     DevP p;
@@ -706,10 +708,15 @@ struct SolveArgs {
     // first window, the pass saves the finished layer (costs + histories of its live cells) and the episode moves
     // on; the wider window loads it and continues from that layer instead of starting over.  Back-pointers of the
     // finished layers stay where tier 0 wrote them (one region per episode).
-    unsigned char *ckpt;   // [N][ckpt_stride] or null: header {layer, wlo, whi, flags} + cost[W0] + hist[W0]
+    // Round 5: only the searches that DO overflow keep anything per episode.  The first window writes its back-pointers per resident workgroup
+    // like every other tier; a search that checkpoints takes an entry of a POOL (pool_cap entries, one atomic ticket per step), copies the
+    // back-pointer rows of its finished layers there (<= H x W0 bytes, once) and saves the layer next to them; resume_t[e] = layer | entry << 8.
+    // An exhausted pool costs that search its resume (it starts over in the wider window), never a result.
+    unsigned char *ckpt;   // [pool_cap][ckpt_stride] or null: header {layer, wlo, whi, flags} + cost[W0] + hist[W0]
     size_t ckpt_stride;
-    int *resume_t;         // [N] layer to resume at (0 = start over); written before the episode is queued
-    const u16 *bp0;        // tier >= 1: tier 0's per-episode back-pointers (row stride W0) or null
+    int *resume_t;         // [N] layer to resume at (0 = start over) | pool entry << 8; written before the episode is queued
+    unsigned char *pool_bp;   // [pool_cap][H][W0] back-pointer rows of checkpointed searches (element size as bp), or null
+    int pool_cap;
     int W0;                // first window (cells)
     int maxshift;          // upper bound of (target cell - source cell) + rounding slack of the interval bookkeeping
     unsigned long long *phase_prof;   // analysis builds: [2][16] clock totals per pass and phase, else null
@@ -783,6 +790,7 @@ struct Ep {
     int S, e;
     bool s1_plain;
     u16 *bp;
+    int pool;          // second window: pool entry of the checkpoint this search continues from
 };
 
 struct PassOut {
@@ -791,6 +799,7 @@ struct PassOut {
     bool pruned;       // some reached node was not expanded (bound / band) or some cell was withheld
     int nodes;         // expanded nodes
     int maxspan;       // widest live span (cells) the pass needed
+    int pool;          // first window, return code 2: pool entry that holds the saved layer and the back-pointer rows
 };
 
 // Workgroup-shared scratch of one episode (LDS in every variant).
@@ -928,7 +937,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     int wlo = 0, whi = 1;
     if (RES == 2 && t_start > 0) {      // continue a pass checkpointed by the first window (see SolveArgs::ckpt)
         int fl = 0;
-        ckpt_load<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
+        ckpt_load<USE_LDS>(a.ckpt + (size_t)ep.pool * a.ckpt_stride, a.W0, cost, hist, WM, &wlo, &whi, &fl);
         if (tid == 0) sh.flags = fl;
     } else if (tid == 0) { M::st64(&cost[0], 0ull); M::st32(&hist[0], 0u); sh.flags = 0; }
     if (tid == 0) { agg_reset(&sh.agg[0]); agg_reset(&sh.agg[4]); }
@@ -1139,9 +1148,28 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 // the layer about to be built is at most (highest source + maxshift) - lowest source.
                 const int top_src = list_at(0), low_src = smin;
                 if (top_src + a.maxshift - low_src > W) {
-                    ckpt_save<USE_LDS>(a.ckpt + (size_t)e * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
+                    // a pool entry for the saved layer and the back-pointer rows written so far (layers 1 .. t-1: layer t's are written
+                    // when it is expanded, i.e. by the window that continues)
+                    if (tid == 0) {
+                        int idx = (int)atomicAdd(&a.counters[STMPC_CNT_POOL], 1u);
+                        if (idx >= a.pool_cap) { idx = -1; atomicAdd(&a.counters[STMPC_CNT_POOL_FULL], 1u); }
+                        sh.work = idx;
+                    }
+                    M::barrier();
+                    const int idx = sh.work;
+                    M::barrier();
+                    if (idx < 0) return 1;      // no room: an ordinary overflow, the wider window starts this search over
+                    ckpt_save<USE_LDS>(a.ckpt + (size_t)idx * a.ckpt_stride, a.W0, cost, hist, WM, t, wlo, whi, (int)sh.flags);
+                    {
+                        const size_t esz = a.bp_rel8 ? 1 : 2, row = (size_t)W * esz;          // (W == W0 in the window that saves)
+                        const uint4 *src = (const uint4 *)((const unsigned char *)bp + row);
+                        uint4 *dst = (uint4 *)(a.pool_bp + (size_t)idx * H * row + row);
+                        const size_t n16 = (size_t)(t - 1) * row / 16;
+                        for (size_t x = tid; x < n16; x += blockDim.x) dst[x] = src[x];
+                    }
                     out.best_t = t;             // the layer that was saved
                     out.nodes = nlist;          // (nodes of the layer that was saved: what is left to do scales with it, see solve_episode)
+                    out.pool = idx;
                     return 2;
                 }
             }
@@ -1913,8 +1941,9 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         // lattice point start+step differs from that goes to the last tier, which is compiled with the general form
         if ((!ep.s1_plain || a.force_general) && phase != 1) return 1;      // (a bound-only phase tolerates the ulp-level difference: bounds are re-checked)
     }
-    // (RES 1: per episode, the next tier reads them; element size 1 or 2 bytes, see SolveArgs::bp_rel8)
-    ep.bp = (u16 *)((unsigned char *)a.bp + (size_t)(RES == 1 ? e : slot) * H * W * (a.bp_rel8 ? 1 : 2));
+    // (per resident workgroup in every tier; element size 1 or 2 bytes, see SolveArgs::bp_rel8.  A first-window search that checkpoints copies its rows to the pool.)
+    ep.bp = (u16 *)((unsigned char *)a.bp + (size_t)slot * H * W * (a.bp_rel8 ? 1 : 2));
+    ep.pool = 0;
     const double start_s = ep.start_s, delta = ep.delta;
     const int S = ep.S;
     auto sval = [&](int n) -> double {
@@ -2002,14 +2031,14 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         }
     }
     int t_res = 0;                      // layer the successful pass started from (checkpoint of the first window) or 0
-    if constexpr (RES == 2) { if (have_bound) t_res = a.resume_t[e]; }
+    if constexpr (RES == 2) { if (have_bound) { const int rt = a.resume_t[e]; t_res = rt & 0xff; ep.pool = rt >> 8; } }
     for (int attempt = 0;; ++attempt) {
         if (attempt > 0) t_res = 0;     // a relaxed bound invalidates the checkpoint: start over
         int rc = dp_pass<USE_LDS, GRID, FASTDIV, KT, PASS_EXACT, FANMAX, S1GEN, RES, NWX>(a, ep, sh, cost, hist, pen, list, chunk_cnt, ltab_e, ltab_w, ltab_n, ubits, 0.0, false, out, t_res);
         if (rc != 0) {
             if constexpr (!GRID) {
                 if (tid == 0 && a.ubound) a.ubound[e] = (ubits == 0ull) ? 1ull : ubits;    // 0 is reserved for "unknown"
-                if constexpr (RES == 1) { if (tid == 0) a.resume_t[e] = (rc == 2) ? out.best_t : 0; }   // rc 2: layer out.best_t is saved
+                if constexpr (RES == 1) { if (tid == 0) a.resume_t[e] = (rc == 2) ? (out.best_t | (out.pool << 8)) : 0; }   // rc 2: layer out.best_t is saved in pool entry out.pool
                 __threadfence();        // checkpoint, back-pointers, bound: visible before the episode is queued
                 __syncthreads();
                 // Longest first in the next window: what is left of this search is roughly (layers left) x (nodes of the saved layer); above
@@ -2056,10 +2085,10 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
             sh.path[t] = n;
             if (a.bp_rel8) {
                 const unsigned char *b8 = (RES != 2 || t >= t_res) ? (const unsigned char *)bp + (size_t)t * W + (n & WM)
-                                                                   : (const unsigned char *)a.bp0 + ((size_t)e * H + t) * a.W0 + (n & (a.W0 - 1));
+                                                                   : (const unsigned char *)a.pool_bp + ((size_t)ep.pool * H + t) * a.W0 + (n & (a.W0 - 1));
                 n -= (int)__hip_atomic_load(b8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (RES != 2 || t >= t_res) n = __hip_atomic_load(&bp[(size_t)t * W + (n & WM)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else n = __hip_atomic_load(&a.bp0[((size_t)e * H + t) * a.W0 + (n & (a.W0 - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else n = __hip_atomic_load(&((const u16 *)a.pool_bp)[((size_t)ep.pool * H + t) * a.W0 + (n & (a.W0 - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         sh.path[0] = n;
     }

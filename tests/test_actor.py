@@ -317,3 +317,37 @@ def test_gpu_sparse_control_with_no_takeover_at_all(gpu_ctx, restore_settings):
     want = [combined.get_ego_speed_from_jerk(10.0, 0.0, -0.5)] * n
     assert np.array_equal(d["speed"].cpu().numpy(), np.array(want))
     assert gpu_ctx.combined_counts() == (n, 0)
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_and_dense_controller_solve_agree_on_a_bench_batch(gpu_ctx, restore_settings):
+    """configs[2]'s bench batch (4096 states, pretrained ddpg_medium1, fused kernel): the sparse controller solve -- only the states whose decision
+    calls st.do_st_control -- and the dense one give the same takeover flags, reasons and commanded speeds, bit for bit; the counters show the saving."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, actor, combined, combined_bench
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1)
+    S = pkg.Settings
+    n = 4096
+    ego, kc, ox, ov, evals0 = combined_bench.bench_states(n, 3000, S)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_ego, d_k, d_ox, d_ov, d_e0 = t(ego), t(kc), t(ox), t(ov), t(evals0)
+    params = _capi.Params.from_settings(S)
+    pol = actor.DDPGActor(combined_bench.COMBINED_MEDIUM_1_ACTOR, n, gpu_ctx, S, dev)
+    res = {}
+    for sparse in (True, False):
+        pol.evals.copy_(d_e0)
+        gpu_ctx.combined_counts(reset=True)
+        d = combined.decide_batch_device(gpu_ctx, params, _capi.CombinedCfg.from_settings(S, sparse_control=sparse), d_ego, d_k, d_ox, d_ov, pol, None,
+                                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        gpu_ctx.check_error()
+        res[sparse] = ({q: d[q].cpu().numpy() for q in ("takeover", "reason", "speed", "first_action")}, gpu_ctx.combined_counts())
+    for q in ("takeover", "reason", "first_action"):
+        assert np.array_equal(res[True][0][q], res[False][0][q]), q
+    assert np.array_equal(res[True][0]["speed"].view(np.uint64), res[False][0]["speed"].view(np.uint64))
+    takeovers = int(res[True][0]["takeover"].sum())
+    assert 100 < takeovers < n // 4
+    assert res[True][1] == (n, takeovers) and res[False][1] == (n, n)

@@ -449,17 +449,20 @@ def test_random_parameter_sets_match_oracle(seed, gpu_ctx, restore_settings):
     _check(res, ref, H)
 
 
-@pytest.mark.parametrize("overlap,resume", [("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")])
-def test_concurrent_overflow_launch_is_exact(overlap, resume, restore_settings, monkeypatch):
+@pytest.mark.parametrize("overlap,resume,pool", [("1", "1", ""), ("0", "1", ""), ("1", "0", ""), ("0", "0", ""), ("1", "1", "7"), ("0", "1", "1")])
+def test_concurrent_overflow_launch_is_exact(overlap, resume, pool, restore_settings, monkeypatch):
     """More episodes than persistent workgroups on the wide lattice: with STMPC_OVERLAP=1 the second LDS window's launch
     runs on a side stream and consumes the overflow queue while the first launch is still filling it; with
-    STMPC_RESUME=1 it continues exact passes from the layer the first window checkpointed instead of starting over.
-    Results must not depend on either."""
+    STMPC_RESUME=1 it continues exact passes from the layer the first window checkpointed (saved, with the back-pointer rows written so
+    far, in an entry of the checkpoint pool) instead of starting over; with a pool of 7 / 1 entries (STMPC_POOL) nearly all overflowing
+    searches find it exhausted and start over.  Results must not depend on any of it."""
     import rl_mpc_lanemerging_amd as pkg
     from rl_mpc_lanemerging_amd import _capi, st, synth
     from oracle import st_oracle as orc
     monkeypatch.setenv("STMPC_OVERLAP", overlap)
     monkeypatch.setenv("STMPC_RESUME", resume)
+    if pool:
+        monkeypatch.setenv("STMPC_POOL", pool)
     pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
     pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
     p = _capi.Params.from_settings(pkg.Settings)
@@ -470,6 +473,10 @@ def test_concurrent_overflow_launch_is_exact(overlap, resume, restore_settings, 
         res = st.solve_arrays(ego, kc, ox, ov, p, ctx)
     s = ctx.stats()
     assert s["fallback"] > 20 and s["hbm_tier"] == 0
+    if pool:
+        assert s["pool_exhausted"] >= 1 and s["pool_exhausted"] <= s["fallback"]
+    else:
+        assert s["pool_exhausted"] == 0
     ref = orc.solve_batch(op, ego, kc, ox, ov, solver="layered", nthreads=16)
     _check(res, ref, 40)
     ctx.close()
