@@ -42,6 +42,40 @@ def test_params_struct_layout_matches_header():
     assert ctypes.sizeof(capi.Params) == 8 * len(names)
 
 
+def _header_struct_fields(name):
+    """Field names and C types of `typedef struct <name> { ... } <name>;` in include/stmpc.h, in order (comments stripped)."""
+    import re
+    header = open(os.path.join(REPO, "include", "stmpc.h")).read()
+    body = header[header.index("typedef struct %s {" % name) + len("typedef struct %s {" % name):header.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for stmt in body.split(";"):
+        stmt = " ".join(stmt.split())
+        if not stmt:
+            continue
+        ctype, rest = stmt.split(" ", 1)
+        out += [(n.strip(), ctype) for n in rest.split(",")]
+    return out
+
+
+def test_every_other_struct_layout_matches_header():
+    """stmpc_stats, stmpc_combined_cfg, stmpc_policy_features_cfg, stmpc_sim_cfg, stmpc_profile_totals: the ctypes mirrors have the header's
+    fields in the header's order with the header's types (a field added on one side only would shift everything after it silently)."""
+    capi = _lib()
+    ctype_of = {"double": ctypes.c_double, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64}
+    for name, cls in (("stmpc_stats", capi.Stats), ("stmpc_combined_cfg", capi.CombinedCfg), ("stmpc_policy_features_cfg", capi.FeaturesCfg),
+                      ("stmpc_sim_cfg", capi.SimCfg), ("stmpc_profile_totals", capi.ProfileTotals)):
+        want = _header_struct_fields(name)
+        have = [(n, t) for n, t in cls._fields_]
+        assert [n for n, _ in want] == [n for n, _ in have], name
+        assert [ctype_of[t] for _, t in want] == [t for _, t in have], name
+    lib = capi.load()
+    f = capi.FeaturesCfg(cars_ahead=2, cars_behind=2, use_acceleration=1, time_feature=1)
+    assert lib.stmpc_policy_features_len(ctypes.byref(f)) == 21          # (host-only helper: no GPU needed)
+    f.use_acceleration, f.time_feature, f.cars_ahead = 0, 0, 3
+    assert lib.stmpc_policy_features_len(ctypes.byref(f)) == 5 * 3 + 4
+
+
 def test_host_helpers_match_reference_golden():
     capi = _lib()
     from rl_mpc_lanemerging_amd import control
