@@ -182,6 +182,11 @@ struct stmpc_ctx {
     // STMPC_CU_RESERVE=n (multiple of 8, experiment): n compute units are kept out of the first window's launch and host the second
     // window's workgroups from the start of the step (CU-masked streams); 0 = off
     int cu_reserve = 0;
+    int side_grid = 0;             // STMPC_SIDE_GRID=n: workgroups of the second window's side launch (0 = automatic: the tier's full grid with the bounded
+                                   // search, 32 on the narrow lattice where a handful of episodes overflow)
+    int *h_overflow = nullptr, *d_overflow = nullptr;   // mapped pinned word: episodes that overflowed the first window in the batch before this one (stored by the
+                                   // batch's last launch straight into host memory -- no copy, no stall --, read, possibly one batch late, when the next one
+                                   // is set up): the narrow lattice starts its second window alongside the first only when there was something for it to do
     double bound_infl = 1.00002;   // STMPC_BOUND_INFL: factor on a bounding pass's single-precision path cost (>= 1.00002, the rounding of that total)
     int qp_maxiters = STMPC_QP_MAXITERS;   // STMPC_QP_ITERS (experiment: the iteration cap of st.do_st_control's QP; the reference's is 10, st.py:17)
     int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
@@ -327,6 +332,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_RETRY")) { double x[3]; if (sscanf(w, "%lf,%lf,%lf", &x[0], &x[1], &x[2]) == 3 && x[0] > 1.0 && x[1] > 1.0 && x[2] > 1.0) for (int i = 0; i < 3; ++i) c->retry_mult[i] = x[i]; }
     if (const char *w = getenv("STMPC_RETIRE_CUS")) { int v = atoi(w); if (v >= 0 && v < 256) c->retire_cus = v; }
     if (const char *w = getenv("STMPC_RETIRE_AT")) { int v = atoi(w); if (v >= 1 && v <= 200) c->retire_at = v; }
+    if (const char *w = getenv("STMPC_SIDE_GRID")) { int v = atoi(w); if (v >= 1) c->side_grid = v; }
     if (const char *w = getenv("STMPC_CU_RESERVE")) {
         // Reserved compute units: bit 32a + a + 8j (a = 0..7, j < n/8) of the CU mask.  Whether the driver numbers the mask bits
         // XCD by XCD or round-robin over the XCDs, every XCD gives up n/8 units and keeps the rest (a queue whose mask leaves an XCD
@@ -365,6 +371,7 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->cc_sel_idx, &c->cc_sel_count, &c->cc_c_ego, &c->cc_c_k, &c->cc_c_ox, &c->cc_c_ov, &c->cc_c_speed, &c->cc_c_fine, &c->cc_c_fine_len};
     for (DevBuf *b : all) b->release();
     if (c->cc_host_count) (void)hipHostFree(c->cc_host_count);
+    if (c->h_overflow) (void)hipHostFree(c->h_overflow);
     if (c->main_masked) (void)hipStreamDestroy(c->main_masked);
     if (c->aux_reserved) (void)hipStreamDestroy(c->aux_reserved);
     if (c->ev_join0) (void)hipEventDestroy(c->ev_join0);
@@ -713,8 +720,17 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
     }
     // second LDS tier started alongside the first (see k_solve): only where overflow is common enough to pay for the
     // extra launch, and not with the two-phase schedule (its first launch of tier 0 only bounds)
+    // (narrow lattice, round 5: three of 4096 benchmark states overflow the first window; run after the first launch they cost one search's latency,
+    // 0.14 of a 1.0 ms step; alongside it, on a small grid, they are done when it ends -- but a side launch that finds nothing to do costs 40 us of
+    // stream hand-overs, so it is started only when the previous batch on this context overflowed)
+    if (!c->h_overflow) {
+        HIPCHK(hipHostMalloc((void **)&c->h_overflow, sizeof(int), hipHostMallocMapped)); *c->h_overflow = 0;
+        HIPCHK(hipHostGetDevicePointer((void **)&c->d_overflow, c->h_overflow, 0));
+    }
+    const bool overlap_auto = prune_on != 0 || (small_fan && *c->h_overflow > 0);
     const bool overlap = nt >= 2 && tierLds[1] && !(prune_on && c->two_phase) && N > tierGrid[0] &&
-                         (c->overlap < 0 ? prune_on != 0 : c->overlap != 0);
+                         (c->overlap < 0 ? overlap_auto : c->overlap != 0);
+    const int side_grid_auto = c->side_grid > 0 ? c->side_grid : (small_fan ? 32 : 0);
     const bool reserve = reserve_cfg && overlap;
     int *queue1 = overlap ? c->lists.as<int>() + (size_t)N : nullptr;
     const bool split = prune_on && !c->two_phase && c->split && N >= 2 * tierGrid[0];
@@ -799,6 +815,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
     a.proxy = c->proxy.as<unsigned>();
     const bool two_phase = a.prune && c->two_phase;      // bound all episodes first, then solve them heaviest-first
     a.path_idx = d_path; a.best_t = d_bt; a.cost = d_cost; a.path_dist = d_pd; a.crash = d_crash; a.action_cost = d_action_cost;
+    a.host_overflow = c->d_overflow;
 
     if (overlap && split && c->retire_cus > 0 && c->retire_cus < c->num_cu) {
         if ((rc = c->cu_tab.ensure(1025 * sizeof(unsigned)))) return rc;
@@ -826,7 +843,8 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         const size_t lds = tierLdsBytes[k];
         const bool std_shape = tierNW[k] == 4 && tierW[k] == 2048 && tierPW[k] == 1024;      // the kernels compiled with these as constants
         const bool std_shape2 = tierNW[k] == 8 && tierW[k] == 8192 && tierPW[k] == 4096;
-        const dim3 grid(on_reserved ? (tierGrid[k] / c->num_cu > 0 ? tierGrid[k] / c->num_cu : 1) * c->cu_reserve : tierGrid[k]), block(64 * tierNW[k]);
+        const int side_g = (side && !on_reserved && side_grid_auto > 0 && side_grid_auto < tierGrid[k]) ? side_grid_auto : tierGrid[k];
+        const dim3 grid(on_reserved ? (tierGrid[k] / c->num_cu > 0 ? tierGrid[k] / c->num_cu : 1) * c->cu_reserve : side_g), block(64 * tierNW[k]);
 #define STMPC_LAUNCH_R(L, FD, KT_, FM, SG, RS)                                                                \
         do {                                                                                                  \
             if (lds > 48 * 1024)                                                                              \

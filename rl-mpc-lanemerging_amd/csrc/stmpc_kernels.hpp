@@ -754,6 +754,7 @@ struct SolveArgs {
     double *cost;          // [N]
     double *path_dist;     // [N][H] or null
     int *crash;            // [N] or null
+    int *host_overflow;    // null or a word in MAPPED HOST memory: the batch's last launch stores the number of episodes that overflowed the first window there
     double *action_cost;   // [N][2] or null: (cell of the first step as a double, -1 if the path has none; cost) -- the fused row the multi-GPU gather moves
     double *s_sequence;    // grid mode: [H]
 };
@@ -2241,6 +2242,8 @@ __global__ void __launch_bounds__(512, ((FANMAX <= 12 && NWX != 88) ? STMPC_MIN_
                 return e_;
             }
         };
+        if (a.last_tier && !a.concurrent && a.host_overflow && blockIdx.x == 0 && tid == 0)      // (every earlier launch of the batch has finished: the count is final)
+            __hip_atomic_store(a.host_overflow, (int)__hip_atomic_load(&a.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t_begin = a.concurrent ? wall_clock64() : 0ull;
         if (a.tier == 0 && a.feeds_concurrent && tid == 0) atomicAdd(&a.counters[STMPC_CNT_RESIDENT], 1u);
         int my_rank = 0;
