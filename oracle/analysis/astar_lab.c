@@ -42,7 +42,7 @@ int astar_table(double ds, double dt, int H, double v_w, double a_w, double j_w,
     return 0;
 }
 
-typedef struct { long long nodes, edges, edges_filt, cut_h, reached; int best_t; double cost; int pruned; } astar_out;
+typedef struct { long long nodes, edges, edges_filt, cut_h, reached; int best_t; double cost; int pruned; long long span_sum, layers; } astar_out;
 
 /* Bounded layered pass (orc_solve_layered with "expand only nodes <= U"), optionally with the cost-to-go test.
  * use_h: 0 plain bound, 1 + cost-to-go at expansion.  deflate: factor (< 1) on F against the rounding of the lattice. */
@@ -70,6 +70,7 @@ int astar_pass(const uint8_t *obstacles, const double *s_values, int S, const do
         for (int i = 0; i < S; i++) nxt_c[i] = INFINITY;
         int32_t *prev_n = previous + (size_t)(t + 1) * S;
         const int r = H - 1 - t;
+        out->span_sum += hi_w - lo_w; out->layers++;
         for (int s = lo_w; s < hi_w; s++) {
             double C = cur_c[s];
             if (!(C < INFINITY)) continue;

@@ -949,6 +949,14 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     int total_nodes = 0;
     int maxspan = 0;
     int last_t = -1;               // PASS_EXACT: deepest layer that had nodes to expand
+    // Dense layers (narrow-lattice kernels, unbounded exact pass: the reference's own lattice).  98 % of the cells between the lowest and the highest
+    // reached cell of a layer ARE reached there (measured on the benchmark batch: 420 nodes in a span of 429), so the list of cells to expand is the
+    // span itself: no scan, no compaction, no list lookup in front of every source's cost and history -- a fifth of this pass's time.  A cell of the
+    // span that was not reached simply leaves its lane idle.  [d_lo, d_hi) = extent of the candidates offered to the layer being expanded.
+    constexpr bool DENSE_OK = (MODE == PASS_EXACT) && (FANMAX == 9) && (RES == 0);
+    const bool dense = DENSE_OK && ubits == INF_BITS;
+    int d_lo = 0, d_hi = 1, nd_lo = 0x7fffffff, nd_hi = 0;
+    int wave_nodes = 0;            // dense layers: sources this wave expanded (the list's length is not the node count there)
 
     const int last_src_layer = (MODE == PASS_BOUND) ? H - 2 : H - 1;
     STMPC_PH(0);                        // 0: pass set-up
@@ -1082,7 +1090,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         const int top0 = (whi + 63) & ~63;
         const int nch = (top0 - (wlo & ~63)) >> 6;
         const int cpw = (nch + NW - 1) / NW;
-        {
+        if (!dense) {
             bool pruned_l = false;
             int wn = 0;
             const int jend = (wave + 1) * cpw < nch ? (wave + 1) * cpw : nch;
@@ -1118,9 +1126,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         segbase[0] = 0;
 #pragma unroll
         for (int w = 0; w < SH::waves; ++w)           // wave-uniform: keep the boundaries in scalar registers
-            segbase[w + 1] = segbase[w] + __builtin_amdgcn_readfirstlane(w < NW ? sh.cnt[w] : 0);
-        const int nlist = segbase[SH::waves];
+            segbase[w + 1] = segbase[w] + (dense ? 0 : __builtin_amdgcn_readfirstlane(w < NW ? sh.cnt[w] : 0));
+        const int nlist = dense ? (d_hi > d_lo ? d_hi - d_lo : 0) : segbase[SH::waves];
         auto list_at = [&](int g) -> int {                   // g-th selected cell of the layer, descending
+            if constexpr (DENSE_OK) { if (dense) return d_hi - 1 - g; }
             int w = 0;
 #pragma unroll
             for (int k = 1; k < SH::waves; ++k) w += (g >= segbase[k]) ? 1 : 0;
@@ -1129,7 +1138,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             for (int k = 1; k < SH::waves; ++k) basew = (w == k) ? segbase[k] : basew;
             return (int)M::ld16(&list[w * cpw * 64 + (g - basew)]);
         };
-        total_nodes += nlist;
+        if (!dense) total_nodes += nlist;
         if constexpr (MODE == PASS_BOUND) {
             // beam-like control of the band: a layer that expanded more than band_cap nodes narrows the next one in
             // proportion, a thin one lets it recover (square root), never beyond the nominal band
@@ -1190,12 +1199,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             const int sub = tid & ((1 << gsh) - 1);
             rstep = per >> gsh;
             const int srcidx = r0 + (tid >> gsh);
-            const bool inlist = srcidx < nlist;
+            bool inlist = srcidx < nlist;
             const int i = inlist ? list_at(srcidx) : 0;
             u64 cb = INF_BITS;
             unsigned h = 0u;
+            if constexpr (DENSE_OK) { if (dense && inlist) { cb = M::ld64(&cost[i & WM]); inlist = cb < INF_BITS; } }
             if (inlist) {
-                cb = M::ld64(&cost[i & WM]);
+                if (!dense) cb = M::ld64(&cost[i & WM]);
                 if constexpr (MODE == PASS_BOUND) h = (unsigned)cb;       // the bounding pass keeps the history in the cell's low word
                 else h = M::ld32(&hist[i & WM]);
             }
@@ -1330,6 +1340,13 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 rstep = (64 * kw) >> gsh;
             }
             const bool act = inlist && wave < kw;
+            if constexpr (DENSE_OK) {
+                if (dense) {                               // what the scan does for a listed layer: the nodes' count, the layer's cheapest node
+                    const bool mine = act && sub == 0;
+                    wave_nodes += __popcll(__ballot(mine));
+                    if (mine && (cb < my_best || (cb == my_best && i < my_best_n))) { my_best = cb; my_best_n = i; }
+                }
+            }
             if constexpr (MODE == PASS_EXACT) {
                 if (act && t > 0 && sub == 0) {
                     if (a.bp_rel8) ((unsigned char *)bp)[(size_t)t * W + (i & WM)] = (unsigned char)(i - pr);
@@ -1347,6 +1364,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 continue;
             }
             const int need_lo = clo, need_hi = chi;              // cells this round's candidates can touch
+            if constexpr (DENSE_OK) { nd_lo = need_lo < nd_lo ? need_lo : nd_lo; nd_hi = need_hi > nd_hi ? need_hi : nd_hi; }
             // the interval of initialised next-layer cells grows in 64-cell blocks where that is safe: never
             // below a_k, the lowest source of this round (lower cells may hold sources that are still unread;
             // cells >= a_k are either in registers or were not selected for expansion)
@@ -1525,10 +1543,35 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             if (mt < INF_BITS) { out.best_t = t + 1; out.best_bits = mt; }
         }
         STMPC_PH(11);                   // 11: end of layer
+        if constexpr (DENSE_OK) {
+            if (dense) {                // the layer's cheapest node per wave (a listed layer's scan leaves it there)
+                const u64 wb = wave_min_u64(my_best);
+                const int wbn = wave_min_i(my_best == wb ? my_best_n : 0x7fffffff);
+                if (lane == 0) { sh.best_bits[t & 1][wave] = wb; sh.best_n[t & 1][wave] = wbn; }
+                d_lo = nd_lo; d_hi = nd_hi; nd_lo = 0x7fffffff; nd_hi = 0;
+            }
+        }
         if (!relax) break;
-        if (first) { wlo = 0; whi = 0; } else { wlo = ilo; whi = ihi; }
+        if (first) { wlo = 0; whi = 0; d_lo = 0; d_hi = 0; } else { wlo = ilo; whi = ihi; }
     }
     M::barrier();
+    if constexpr (DENSE_OK) {
+        if (dense) {
+            // node count over the workgroup; and a last layer whose span held candidates' cells but no reached node (all of them blocked) is not
+            // the deepest layer: the other parity still holds the layer before it
+            if (tid == 0) sh.nlist = 0;
+            M::barrier();
+            if (lane == 0 && wave_nodes) atomicAdd(&sh.nlist, wave_nodes);
+            M::barrier();
+            total_nodes = sh.nlist;
+            if (last_t > 0) {
+                u64 any = ~0ull;
+                for (int w = 0; w < NW; ++w) { const u64 b_ = sh.best_bits[last_t & 1][w]; any = b_ < any ? b_ : any; }
+                if (any == ~0ull) last_t -= 1;
+            }
+            M::barrier();
+        }
+    }
     STMPC_PH_FLUSH(MODE);
     if constexpr (MODE == PASS_EXACT) {
         // the terminal of the search (st_cy.pyx:365-369): cheapest node of the deepest non-empty layer, smallest cell among equals
