@@ -1531,6 +1531,8 @@ int stmpc_policy_features_len(const stmpc_policy_features_cfg *f) {
     return (f->cars_ahead + f->cars_behind) * (f->use_acceleration ? 4 : 3) + 4 + (f->time_feature ? 1 : 0);
 }
 
+}  // extern "C"
+
 // ---- the policy network itself (optional: the caller may keep it in its own framework and only use stmpc_policy_features_device) ----
 struct stmpc_actor {
     int device = 0;
@@ -1560,6 +1562,8 @@ int upload(DevBuf &b, const std::vector<float> &v) {
     return STMPC_OK;
 }
 }  // namespace
+
+extern "C" {
 
 int stmpc_actor_create(stmpc_ctx *c, int n_in, int h1, int h2, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                        const float *b2, double tanh_scale, double tanh_mean, stmpc_actor **out) {

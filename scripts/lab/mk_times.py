@@ -14,7 +14,7 @@ s=s.replace(old,new)
 old4="            if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_NODES_BOUND], (unsigned)bn);\n"
 assert old4 in s
 s=s.replace(old4, old4+"            if (tid == 0 && a.tier == 0) { a.dbg_t[(size_t)e * 16 + 12] = (unsigned long long)out.maxspan | ((unsigned long long)bn << 32); a.dbg_t[(size_t)e * 16 + 13] = ubits; a.dbg_t[(size_t)e * 16 + 14] = (unsigned long long)(ubits != INF_BITS); }   // dbg span\n")
-old5="        total_nodes += nlist;\n"
+old5="        if (!dense) total_nodes += nlist;\n"
 assert old5 in s
 s=s.replace(old5, old5+"        if constexpr (MODE == PASS_EXACT && !GRID) { if (tid == 0 && a.tier == 0 && (t == 8 || t == 12 || t == 16)) { unsigned long long *q_ = a.dbg_t + (size_t)e * 16 + 15; const int sh_ = (t == 8 ? 0 : (t == 12 ? 20 : 40)); *q_ = (*q_ & ~(0xFFFFFull << sh_)) | ((unsigned long long)(total_nodes & 0xFFFFF) << sh_); } }   // dbg nodes\n", 1)
 old6="        if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);\n"
