@@ -868,7 +868,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 88>), grid, block, lds, lst, a);       \
         } while (0)
 #ifndef STMPC_FAN88
-#define STMPC_FAN88 16      /* candidate slots per barrier pair in the standard second window (it has the registers: 256 VGPRs) */
+#define STMPC_FAN88 24      /* candidate slots per barrier pair in the standard second window (it has the registers: 256 VGPRs); 12 / 16 / 21 / 24 measured, EXPERIMENTS.md */
 #endif
 #define STMPC_LAUNCH_R0(L, FD, KT_, FM, SG)                                                                   \
         do {                                                                                                  \

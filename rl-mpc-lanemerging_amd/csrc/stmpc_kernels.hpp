@@ -1449,11 +1449,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 unsigned improved = 0u, tied = 0u;
                 STMPC_PH_COUNT(13);
                 // stage A: candidates in batches of UB so that the LDS round trips of a batch overlap
-#ifdef STMPC_UB88
-                constexpr int UB = (NWX == 88) ? STMPC_UB88 : ((FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX));
-#else
                 constexpr int UB = (FANMAX % 4 == 0) ? 4 : (FANMAX % 3 == 0 ? 3 : FANMAX);   // small batches: slots beyond a wave's widest range are skipped
-#endif
 #pragma unroll
                 for (int ub = 0; ub < FANMAX; ub += UB) {
                     if (__ballot(cand(cbase + ub) < hi)) {

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../.."
 {
   echo "# scripts/isa/spill_report.sh: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math --cuda-device-only -S csrc/stmpc.hip, source hash $(python -c 'import rl_mpc_lanemerging_amd as p; print(p.build.source_hash())')"
   echo "# lane = v_readlane_b32 / v_writelane_b32 (SGPR spill moves), scratch = scratch_load / scratch_store (VGPR spills)"
-  for k in "k_solveILb1ELb0ELb1ELi0ELi8ELb0ELi1ELi4E" "k_solveILb1ELb0ELb1ELi0ELi16ELb0ELi2ELi88E" "k_predictILi8E"; do
+  for k in "k_solveILb1ELb0ELb1ELi0ELi8ELb0ELi1ELi4E" "k_solveILb1ELb0ELb1ELi0ELi24ELb0ELi2ELi88E" "k_predictILi8E"; do
     echo; python scripts/isa/census.py /tmp/isa/stmpc.s $k
     echo; python scripts/isa/loops.py /tmp/isa/stmpc.s $k
   done
