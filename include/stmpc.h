@@ -72,7 +72,7 @@
 extern "C" {
 #endif
 
-#define STMPC_ABI_VERSION 4   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
+#define STMPC_ABI_VERSION 5   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
 
 #define STMPC_OK        0
 #define STMPC_EINVAL   -1   /* bad argument (NULL, size, Kmax/H/S out of range) */
@@ -397,16 +397,20 @@ int stmpc_combined_read_state(stmpc_ctx *ctx, int N, int32_t *live, int32_t *his
  * episodes can be run for N environments in lock-step on the device.  The world restates what the reference configures SUMO to do
  * (the "simple traffic distribution", config.py:39): highway vehicles of vType "normal" follow SUMO's Krauss model (Euler form,
  * sigma 0) behind the vehicle ahead and behind the ego once that is on the junction, they enter as control.py:215-226 adds them,
- * the ego obeys its acceleration limits only (speed mode 22, control.py:43) and moves along the straight lines the planner assumes
- * (prediction.py:46-59).  It is not SUMO: episode statistics compare with the reference's reports as distributions only.
+ * the ego obeys its acceleration limits only (speed mode 22, control.py:43) and moves along `ego_route` -- the centre line of its lanes in
+ * the reference's network (ramp_0 and the junction's internal lane, merge.net.xml:42,52), whose (x, y) pairs are what TraCI reports and what
+ * the reference's planner and trained actors see -- or, without a route, along the straight lines the planner assumes (prediction.py:46-59).
+ * It is not SUMO: episode statistics compare with the reference's reports as distributions only.
  *   stmpc_sim_init_device   traffic in its stationary state, ego at the ramp start with control.get_ego_start_speed's draw
  *   stmpc_sim_view_device   planner inputs of every environment (the layout stmpc_solve_batch_device takes; vehicles within the
  *                           sensor radius, front to back; other_a may be NULL)
  *   stmpc_sim_step_device   one tick with the commanded speeds (limited by the vehicle's acceleration limits); finished environments idle
- *   stmpc_sim_read          host copies: status [N] (0 running, 1 arrived = "merged", 2 crashed, 3 out of time), ticks [N], acc [N][8] = sum of
- *                           speeds, max speed, sum |jerk|, (internal), samples, closest distance past CRASH_MIN_S, sum and count of those
- *                           distances, and ego [N][4]
+ *   stmpc_sim_read          host copies: status [N] (0 running, 1 arrived = "merged", 2 crashed, 3 out of time), ticks [N], acc [N][STMPC_SIM_NACC] =
+ *                           sum of speeds, max speed, sum |jerk|, (internal), samples, closest distance past CRASH_MIN_S, sum and count of those
+ *                           distances; then the reference's "disruption" columns (control.py:289-304, stats.py:64-68: deceleration of the nearest
+ *                           vehicle behind the ego while ego_s > disruption_min_s): sum, maximum, samples, samples with a non-zero value; and ego [N][4]
  */
+#define STMPC_SIM_NACC 12
 typedef struct stmpc_sim_cfg {
     double tick_length;              /* Settings.TICK_LENGTH */
     double other_car_speed;          /* Settings.OTHER_CAR_SPEED */
@@ -420,16 +424,25 @@ typedef struct stmpc_sim_cfg {
      * defaults: emergencyDecel 9, width 1.8); speed_dev = deviation of the per-vehicle speed factor (0 in the simple distribution) */
     double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
     int32_t vary_traffic_start_times, randomize_start_speed, max_ticks;
-    int32_t yield_overlap;           /* a highway vehicle whose front is behind the ego's front but ahead of its rear (the two overlap along the converging lanes):
-                                        1 = it treats the ego as its leader at once (SUMO's link leader with a negative gap), 0 = only where the lanes are less than
-                                        a vehicle width apart */
+    int32_t yield_overlap;           /* what a highway vehicle does about an ego that is on the junction but whose rear (plus minGap) is not yet ahead of the vehicle's
+                                        front -- the ego "laps in": 0 = nothing until the lanes are less than a vehicle width apart; 1 = it follows the ego at once
+                                        (Krauss with a negative gap: brakes for a slow ego, not for a fast one); 2 = SUMO's link-leader rule as its effect shows in the
+                                        reference's "disruption" columns: a vehicle whose front is behind the ego's front is asked to STOP while the ego laps in
+                                        (emergency braking, whatever the ego's speed); 3 = as 2 for every vehicle that overlaps the ego at all.  The package's
+                                        default is 2 (DESIGN.md section 9 compares the four) */
     uint64_t seed;
+    const double *ego_route_xy;      /* HOST [ego_route_n][2]: polyline of the ego's lane centre line from the ramp's start to the junction exit, x strictly
+                                        increasing (beyond its last point the ego keeps that point's y); read by stmpc_sim_init_device, which keeps a device
+                                        copy for the following view / step calls.  NULL / fewer than 2 points: straight lines towards (1.5, -1.5) */
+    int32_t ego_route_n;
+    int32_t reserved0;
+    double disruption_min_s;         /* Settings.MERGE_POINT_X (-50): the "disruption" columns are recorded while the ego's s exceeds it (control.py:289) */
 } stmpc_sim_cfg;
 int stmpc_sim_init_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, void *stream);
 int stmpc_sim_view_device(stmpc_ctx *ctx, const stmpc_sim_cfg *cfg, int N, int Kmax, double *d_ego5, int32_t *d_k_count,
                           double *d_other_x, double *d_other_v, double *d_other_a, void *stream);
 int stmpc_sim_step_device(stmpc_ctx *ctx, const stmpc_params *p, const stmpc_sim_cfg *cfg, int N, const double *d_cmd_speed, void *stream);
-int stmpc_sim_read(stmpc_ctx *ctx, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4);
+int stmpc_sim_read(stmpc_ctx *ctx, int N, int32_t *status, int32_t *ticks, double *acc /* [N][STMPC_SIM_NACC] */, double *ego4);
 /* status [N] into a DEVICE array, asynchronously on `stream`: lets a controller loop mask its own per-environment statistics to the
  * environments that are still running without a host round trip. */
 int stmpc_sim_status_device(stmpc_ctx *ctx, int N, int32_t *d_status, void *stream);

@@ -89,7 +89,23 @@ class SimCfg(C.Structure):
                 ("max_start_speed", C.c_double), ("veh_accel", C.c_double), ("veh_decel", C.c_double), ("veh_min_gap", C.c_double), ("veh_tau", C.c_double),
                 ("veh_emergency_decel", C.c_double), ("veh_length", C.c_double), ("veh_width", C.c_double), ("speed_dev", C.c_double),
                 ("vary_traffic_start_times", C.c_int32), ("randomize_start_speed", C.c_int32),
-                ("max_ticks", C.c_int32), ("yield_overlap", C.c_int32), ("seed", C.c_uint64)]
+                ("max_ticks", C.c_int32), ("yield_overlap", C.c_int32), ("seed", C.c_uint64),
+                ("ego_route_xy", C.POINTER(C.c_double)), ("ego_route_n", C.c_int32), ("reserved0", C.c_int32),
+                ("disruption_min_s", C.c_double)]
+
+    def set_route(self, xy):
+        """``xy``: [n][2] polyline of the ego's lane centre line (x strictly increasing), or None for the planner's straight lines.
+        The array is kept alive by this object; ``stmpc_sim_init_device`` copies it to the device."""
+        if xy is None:
+            self._route = None
+            self.ego_route_xy, self.ego_route_n = None, 0
+        else:
+            import numpy as np
+            self._route = np.ascontiguousarray(xy, dtype=np.float64)
+            assert self._route.ndim == 2 and self._route.shape[1] == 2
+            self.ego_route_xy = self._route.ctypes.data_as(C.POINTER(C.c_double))
+            self.ego_route_n = int(self._route.shape[0])
+        return self
 
 
 class ProfileTotals(C.Structure):
@@ -109,7 +125,8 @@ EXPORTS = (
     "stmpc_policy_features_device", "stmpc_policy_features_len", "stmpc_combined_counts", "stmpc_solve_batch_device_ac",
     "stmpc_actor_create", "stmpc_actor_destroy", "stmpc_actor_eval_device",
 )
-ABI_VERSION = 4     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
+SIM_NACC = 12        # STMPC_SIM_NACC
+ABI_VERSION = 5     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
 QP_NMAX = 64        # STMPC_QP_NMAX
 QP_MAXITERS = 10    # STMPC_QP_MAXITERS (solvers.options['maxiters'], st.py:17)
@@ -493,7 +510,7 @@ class Context:
 
     def sim_read(self, N):
         status, ticks = np.zeros(N, np.int32), np.zeros(N, np.int32)
-        acc, ego4 = np.zeros((N, 8)), np.zeros((N, 4))
+        acc, ego4 = np.zeros((N, SIM_NACC)), np.zeros((N, 4))
         self._chk(self._lib.stmpc_sim_read(self._h, int(N), _iptr(status), _iptr(ticks), _dptr(acc), _dptr(ego4)))
         return status, ticks, acc, ego4
 

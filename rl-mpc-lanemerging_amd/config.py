@@ -38,6 +38,7 @@ class Settings:
     D_WEIGHT = 10.0
     MIN_ALLOWED_DISTANCE = 5
     CRASH_MIN_S = 12
+    MERGE_POINT_X = -50            # config.py:34: the episode runner records the "disruption" columns past this s (control.py:289)
 
     # The policy's state vector, dqn.get_state_vector_from_base_state (config.py:48-49, 136-139)
     SENSOR_RADIUS = 125

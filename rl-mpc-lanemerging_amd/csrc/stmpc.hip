@@ -136,8 +136,8 @@ struct stmpc_ctx {
     int *cc_host_count = nullptr;  // pinned host word for the number of those states
     int64_t cc_ticks = 0, cc_control_solves = 0;      // decisions taken / controller solves run for them (stmpc_combined_counts)
     // batched episode simulator (stmpc_sim_*)
-    DevBuf sim_ego, sim_nveh, sim_vx, sim_vv, sim_va, sim_vc, sim_delay, sim_status, sim_ticks, sim_rng, sim_acc;
-    int sim_N = 0;
+    DevBuf sim_ego, sim_nveh, sim_vx, sim_vv, sim_va, sim_vc, sim_delay, sim_status, sim_ticks, sim_rng, sim_acc, sim_route;
+    int sim_N = 0, sim_route_n = 0;
     DevBuf f_seq, f_len, f_v0, f_a0, f_bac, f_out, f_olen, f_iters, f_speed;   // finer_fit / st_control staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     stmpc_stats stats{};
@@ -367,7 +367,7 @@ void stmpc_destroy(stmpc_ctx *c) {
                      &c->ckpt, &c->pool_bp, &c->resume_t, &c->phase_prof, &c->prio_key, &c->cc_live, &c->cc_hist_len, &c->cc_crash_pred, &c->cc_have_test, &c->cc_sel, &c->cc_rollout_s, &c->cc_test_ego,
                      &c->cc_test_ox, &c->cc_test_ov, &c->cc_probe_ego, &c->cc_probe_ox, &c->cc_probe_ov, &c->cc_path, &c->cc_bt, &c->cc_cost, &c->cc_pcrash, &c->cc_speed,
                      &c->cc_fine, &c->cc_fine_len, &c->cc_err, &c->sim_ego, &c->sim_nveh, &c->sim_vx, &c->sim_vv, &c->sim_va, &c->sim_vc, &c->sim_delay, &c->sim_status, &c->sim_ticks,
-                     &c->sim_rng, &c->sim_acc, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed,
+                     &c->sim_rng, &c->sim_acc, &c->sim_route, &c->f_seq, &c->f_len, &c->f_v0, &c->f_a0, &c->f_bac, &c->f_out, &c->f_olen, &c->f_iters, &c->f_speed,
                      &c->cc_sel_idx, &c->cc_sel_count, &c->cc_c_ego, &c->cc_c_k, &c->cc_c_ox, &c->cc_c_ov, &c->cc_c_speed, &c->cc_c_fine, &c->cc_c_fine_len};
     for (DevBuf *b : all) b->release();
     if (c->cc_host_count) (void)hipHostFree(c->cc_host_count);
@@ -1809,7 +1809,12 @@ int make_simcfg(const stmpc_sim_cfg *g, sim::Cfg *c) {
     c->veh_accel = g->veh_accel; c->veh_decel = g->veh_decel; c->veh_min_gap = g->veh_min_gap; c->veh_tau = g->veh_tau; c->veh_emergency_decel = g->veh_emergency_decel;
     c->veh_length = g->veh_length; c->veh_width = g->veh_width; c->speed_dev = g->speed_dev;
     c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->yield_overlap = g->yield_overlap; c->seed = g->seed;
+    c->route = nullptr; c->route_n = 0;          // (the device copy of the route belongs to the context: sim_route_of)
+    c->disruption_min_s = g->disruption_min_s;
     return STMPC_OK;
+}
+void sim_route_of(stmpc_ctx *c, sim::Cfg *sc) {
+    if (c->sim_route_n >= 2) { sc->route = c->sim_route.as<double>(); sc->route_n = c->sim_route_n; }
 }
 sim::State sim_state(stmpc_ctx *c) {
     return sim::State{c->sim_ego.as<double>(), c->sim_nveh.as<int>(), c->sim_vx.as<double>(), c->sim_vv.as<double>(), c->sim_va.as<double>(), c->sim_vc.as<double>(), c->sim_delay.as<double>(),
@@ -1837,8 +1842,23 @@ int stmpc_sim_init_device(stmpc_ctx *c, const stmpc_sim_cfg *g, int N, void *str
     if ((rc = c->sim_status.ensure((size_t)N * 4))) return rc;
     if ((rc = c->sim_ticks.ensure((size_t)N * 4))) return rc;
     if ((rc = c->sim_rng.ensure((size_t)N * 4))) return rc;
-    if ((rc = c->sim_acc.ensure((size_t)N * 8 * 8))) return rc;
+    if ((rc = c->sim_acc.ensure((size_t)N * sim::NACC * 8))) return rc;
     c->sim_N = N;
+    c->sim_route_n = 0;
+    if (g->ego_route_xy && g->ego_route_n >= 2) {
+        const int n = g->ego_route_n;
+        if (n > 4096) return fail(STMPC_EINVAL, "ego_route_n out of range (at most 4096 points)");
+        std::vector<double> xy((size_t)2 * n);
+        for (int i = 0; i < n; ++i) {
+            xy[i] = g->ego_route_xy[2 * i]; xy[n + i] = g->ego_route_xy[2 * i + 1];
+            if (i && !(xy[i] > xy[i - 1])) return fail(STMPC_EINVAL, "ego_route_xy: x must be strictly increasing");
+        }
+        if ((rc = c->sim_route.ensure(xy.size() * 8))) return rc;
+        HIPCHK(hipMemcpyAsync(c->sim_route.p, xy.data(), xy.size() * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // (xy is a local)
+        c->sim_route_n = n;
+    }
+    sim_route_of(c, &sc);
     hipLaunchKernelGGL(sim::k_sim_init, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sc, N, sim_state(c));
     HIPCHK(hipGetLastError());
     return STMPC_OK;
@@ -1851,6 +1871,7 @@ int stmpc_sim_view_device(stmpc_ctx *c, const stmpc_sim_cfg *g, int N, int Kmax,
     sim::Cfg sc;
     int rc = make_simcfg(g, &sc);
     if (rc) return rc;
+    sim_route_of(c, &sc);
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(sim::k_sim_view, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sc, N, Kmax, sim_state(c), d_ego5, d_k, d_ox, d_ov, d_oa);
     HIPCHK(hipGetLastError());
@@ -1864,6 +1885,7 @@ int stmpc_sim_step_device(stmpc_ctx *c, const stmpc_params *p, const stmpc_sim_c
     DevP dp;
     int rc = make_simcfg(g, &sc);
     if (rc) return rc;
+    sim_route_of(c, &sc);
     if ((rc = make_devp(p, &dp))) return rc;
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(sim::k_sim_step, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, dp, sc, N, sim_state(c), d_cmd_speed, p->crash_min_s);
@@ -1879,14 +1901,14 @@ int stmpc_sim_status_device(stmpc_ctx *c, int N, int32_t *d_status, void *stream
     return STMPC_OK;
 }
 
-int stmpc_sim_read(stmpc_ctx *c, int N, int32_t *status, int32_t *ticks, double *acc8, double *ego4) {
+int stmpc_sim_read(stmpc_ctx *c, int N, int32_t *status, int32_t *ticks, double *acc, double *ego4) {
     if (!c) return fail(STMPC_EINVAL, "ctx is NULL");
     if (N != c->sim_N) return fail(STMPC_EINVAL, "N does not match stmpc_sim_init_device");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     if (status) HIPCHK(hipMemcpy(status, c->sim_status.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     if (ticks) HIPCHK(hipMemcpy(ticks, c->sim_ticks.p, (size_t)N * 4, hipMemcpyDeviceToHost));
-    if (acc8) HIPCHK(hipMemcpy(acc8, c->sim_acc.p, (size_t)N * 64, hipMemcpyDeviceToHost));
+    if (acc) HIPCHK(hipMemcpy(acc, c->sim_acc.p, (size_t)N * sim::NACC * 8, hipMemcpyDeviceToHost));
     if (ego4) HIPCHK(hipMemcpy(ego4, c->sim_ego.p, (size_t)N * 32, hipMemcpyDeviceToHost));
     return STMPC_OK;
 }

@@ -259,9 +259,11 @@ __global__ void __launch_bounds__(64) k_cc_scatter(int M, const int *__restrict_
 // SUMO's vType "normal" of merge_impossible.rou.xml:3 -- car-following model Krauss, accel 4.5, decel 6.0, minGap 1, tau 0.5,
 // sigma 0, speedFactor 1 / speedDev 0, maxSpeed = OTHER_CAR_SPEED -- added at the start of the highway every
 // BASE_TRAFFIC_INTERVAL (+ U(0,1)) seconds (control.py:215-226), and the ego under speed mode 22 (control.py:43: it obeys its
-// acceleration limits and nothing else).  The Krauss follow speed is SUMO's Euler form (MSCFModel::maximumSafeStopSpeedEuler /
-// maximumSafeFollowSpeed), a highway vehicle regards as its leader the vehicle ahead and, once the ego is on the junction's internal
-// lane or beyond, the ego if that is ahead of it (SUMO's link-leader rule for merging internal lanes of equal length); bodies collide
+// acceleration limits and nothing else) moving along the centre line of its lanes (Cfg::route: ramp_0 and the junction's internal lane of
+// merge.net.xml -- the positions TraCI reports and the reference's planner and actors see).  The Krauss follow speed is SUMO's Euler form
+// (MSCFModel::maximumSafeStopSpeedEuler / maximumSafeFollowSpeed), a highway vehicle regards as its leader the vehicle ahead and, once the
+// ego is on the junction's internal lane or beyond, the ego if that is ahead of it; what it does while the ego laps in is Cfg::yield_overlap
+// (four rules, compared with the reference's "disruption" columns in DESIGN.md section 9); bodies collide
 // when they overlap along the lane while the converging lanes are less than a vehicle width apart.  This is a restatement of
 // SUMO's documented models, not SUMO: episode statistics compare with the reference's reports as DISTRIBUTIONS -- and are labelled so.
 // One thread per environment; vehicles live in [N][KS] arrays, front to back.
@@ -273,7 +275,11 @@ struct Cfg {
     double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
     int vary_interval, randomize_start_speed, max_ticks, yield_overlap;
     unsigned long long seed;
+    const double *route;           // device [2][route_n]: x then y of the ego's lane centre line (nullptr: straight lines)
+    int route_n;
+    double disruption_min_s;
 };
+constexpr int NACC = 12;           // statistics per environment (STMPC_SIM_NACC)
 struct State {                     // device arrays
     double *ego4;                  // [N][4] x, y, v, a
     int *nveh;                     // [N]
@@ -282,7 +288,8 @@ struct State {                     // device arrays
     int *status;                   // [N] 0 running, 1 arrived ("merged"), 2 crashed, 3 out of time
     int *ticks;                    // [N] controlled ticks so far
     unsigned *rng;                 // [N] draws so far
-    double *acc;                   // [N][8]: sum speed, max speed, sum |jerk|, previous acceleration, samples, min gap (s > CRASH_MIN_S), sum gap, gap samples
+    double *acc;                   // [N][NACC]: sum speed, max speed, sum |jerk|, previous acceleration, samples, min gap (s > CRASH_MIN_S), sum gap, gap samples,
+                                   //            disruption (deceleration of the nearest vehicle behind, s > disruption_min_s): sum, max, samples, non-zero samples
 };
 __device__ __forceinline__ double uniform01(unsigned long long seed, int env, unsigned &ctr) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)env * 0x100000001ull + (unsigned long long)(ctr++) + 1ull);
@@ -348,8 +355,8 @@ __global__ void __launch_bounds__(64) k_sim_init(Cfg c, int N, State s) {
     }
     s.ego4[e * 4 + 0] = c.ego_start_x; s.ego4[e * 4 + 1] = c.ego_start_y; s.ego4[e * 4 + 2] = v0; s.ego4[e * 4 + 3] = 0.0;
     s.status[e] = 0; s.ticks[e] = 0; s.rng[e] = ctr;
-    for (int q = 0; q < 8; ++q) s.acc[(size_t)e * 8 + q] = 0.0;
-    s.acc[(size_t)e * 8 + 5] = 1e300;
+    for (int q = 0; q < NACC; ++q) s.acc[(size_t)e * NACC + q] = 0.0;
+    s.acc[(size_t)e * NACC + 5] = 1e300;
 }
 // The planner's view of each environment (HighwayState.from_sumo, prediction.py:112-142): the vehicles within the sensor radius of the ego (plane
 // distance; the highway lane runs at y = -1.6), front to back, and the ego with its s coordinate.
@@ -382,9 +389,24 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     const double hi = v_prev + p.a_max * dt, lo = v_prev + p.a_min * dt;
     sel = sel > hi ? hi : (sel < lo ? lo : sel);
     sel = sel < 0 ? 0 : (sel > p.v_max ? p.v_max : sel);
-    // ego motion along its route (the straight lines the planner assumes, prediction.py:46-59)
+    // ego motion along its route: the lane centre line of the reference's network, or the straight lines the planner assumes (prediction.py:46-59)
     double px, py;
-    if (cx < 1.5) {
+    if (c.route && cx < c.route[c.route_n - 1]) {
+        const double *RX = c.route, *RY = c.route + c.route_n;
+        int i = 0;
+        while (i + 2 < c.route_n && RX[i + 1] <= cx) ++i;                        // segment [i, i + 1] holds the ego (x strictly increasing)
+        double left = sel * dt;
+        px = cx; py = cy;
+        while (left > 0.0 && i + 1 < c.route_n) {
+            const double ex = RX[i + 1] - px, ey = RY[i + 1] - py;
+            const double seg = sqrt(__builtin_fma(ey, ey, ex * ex));
+            if (left < seg) { px += ex / seg * left; py += ey / seg * left; left = 0.0; break; }
+            left -= seg; px = RX[i + 1]; py = RY[i + 1]; ++i;
+        }
+        px += left;                                                               // past the junction exit: along the highway lane
+    } else if (c.route) {
+        py = cy; px = cx + sel * dt;
+    } else if (cx < 1.5) {
         double d0 = 1.5 - cx, d1 = -1.5 - cy;
         const double nrm = sqrt(__builtin_fma(d1, d1, d0 * d0));
         d0 /= nrm; d1 /= nrm;
@@ -400,6 +422,7 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     double lead_x = __builtin_inf(), lead_v = 0.0;                               // the vehicle ahead at the start of the step
     bool crashed = false;
     double gap_ahead = 100.0, gap_behind = 100.0;                                // distances to the nearest vehicles in front of / behind the ego (control.py:289-303)
+    double behind_acc = 0.0; bool have_behind = false;                           // acceleration of the nearest vehicle behind the ego (get_closest_cars, prediction.py:162-182)
     const double ego_pos1 = ego_lane_pos(px, py);
     // lateral distance of the converging lanes at the ego's position: bodies can touch only where it is below a vehicle width
     const double lat = px < 1.5 ? 3.31 * (1.5 - px) / 52.08 : 0.0;
@@ -416,7 +439,18 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
         // the ego is a leader too (it may be closer than the vehicle ahead) once its rear is ahead of this vehicle's front -- or, if the two
         // overlap along the lane, once the converging lanes are less than a vehicle width apart there (SUMO's sublane junction model: a foe
         // that is laterally clear is beside the vehicle, not in front of it)
-        if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
+        if (ego_on_lane && c.yield_overlap >= 2) {
+            // SUMO's link leader on merging internal lanes, restated from its observable effect (the reference's "disruption" columns: the vehicle
+            // behind an ego that cuts in brakes at its EMERGENCY deceleration for ~3 ticks however fast the ego is; MSVehicle::getSafeFollowSpeed's
+            // branch for a negative gap asks for a stop, not for a follow speed): with room behind the ego's rear (net of minGap) the vehicle
+            // follows it like any leader; while the ego laps in, a vehicle whose front is behind the ego's front (rule 2) -- or that overlaps
+            // the ego at all (rule 3) -- is asked to stop, i.e. brakes as hard as it can until the ego's rear is clear
+            const double g_net = ego_pos0 - c.veh_length - ox_ - c.veh_min_gap;
+            double vs = __builtin_inf();
+            if (g_net >= 0.0) vs = krauss_follow(c, g_net, v_prev);
+            else if (ego_pos0 > ox_ || (c.yield_overlap == 3 && ego_pos0 > ox_ - c.veh_length)) vs = 0.0;
+            vnext = vs < vnext ? vs : vnext;
+        } else if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
             const double vs = krauss_follow(c, ego_pos0 - c.veh_length - ox_ - c.veh_min_gap, v_prev);
             vnext = vs < vnext ? vs : vnext;
         }
@@ -430,6 +464,11 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
         if (px >= -50.58 && lat < c.veh_width && fabs(nx - ego_pos1) < c.veh_length) crashed = true;
         const double d = fabs(nx - px);                                           // (the reference's closest-vehicle metric uses raw x differences)
         if (nx >= px) gap_ahead = d < gap_ahead ? d : gap_ahead; else gap_behind = d < gap_behind ? d : gap_behind;
+        if (!have_behind && nx < px) {                                            // (front to back: the first one behind; seen only within the sensor radius)
+            have_behind = true;
+            const double ddx = nx - px, ddy = -1.6 - py;
+            behind_acc = sqrt(ddx * ddx + ddy * ddy) < c.sensor_radius ? (vnext - ov_) / dt : 0.0;
+        }
     }
     const double gap = gap_ahead < gap_behind ? gap_ahead : gap_behind;
     // vehicles leaving at the end of the highway (front of the list) and entering at its start, control.py:215-226
@@ -452,12 +491,16 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     s.delay[e] = delay; s.rng[e] = ctr; s.nveh[e] = nn;
     s.ego4[e * 4 + 0] = px; s.ego4[e * 4 + 1] = py; s.ego4[e * 4 + 2] = sel; s.ego4[e * 4 + 3] = acc_ego;
     // episode statistics, control.py:276-305 / stats.py:43-75
-    double *a = s.acc + (size_t)e * 8;
+    double *a = s.acc + (size_t)e * NACC;
     const int tk = s.ticks[e];
     a[0] += sel; a[1] = sel > a[1] ? sel : a[1];
     if (tk > 0) a[2] += fabs((acc_ego - a[3]) / dt);
     a[3] = acc_ego; a[4] += 1.0;
     if (es > crash_min_s) { a[5] = gap < a[5] ? gap : a[5]; a[6] += gap; a[7] += 1.0; }
+    if (es > c.disruption_min_s) {
+        const double dis = behind_acc < 0.0 ? -behind_acc : 0.0;
+        a[8] += dis; a[9] = dis > a[9] ? dis : a[9]; a[10] += 1.0; if (dis != 0.0) a[11] += 1.0;
+    }
     s.ticks[e] = tk + 1;
     if (crashed) s.status[e] = 2;
     else if (px >= c.arrive_x) s.status[e] = 1;

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from . import _capi, synth
+from . import _capi, scenario, synth
 from .config import Settings
 
 # scenario constants of the reference's SUMO network and episode runner
@@ -22,17 +22,24 @@ ARRIVE_X = 1.5 + 50.0                       # arrivalPos = 50 on highwayahead (c
 RAMP_START = (-250.47, 28.47)               # first point of lane ramp_0 (merge.net.xml:52)
 
 
-def ego_start_position():
-    """Point 40 m along the ramp from its start, on the straight line the predictor moves the ego along."""
+def ego_start_position(route="lane"):
+    """Point 40 m along the ramp from its start: on the lane's centre line (``route="lane"``, what SUMO does) or on the straight line from the
+    ramp's start to the junction entry (``route=None``: the world of rounds 3-4, whose ego moves as the predictor assumes)."""
+    if route == "lane":
+        return scenario.point_at_arc(EGO_START_ARC)
     x0, y0 = RAMP_START
     d = np.hypot(-50.58 - x0, 1.71 - y0)
     ux, uy = (-50.58 - x0) / d, (1.71 - y0) / d
     return x0 + EGO_START_ARC * ux, y0 + EGO_START_ARC * uy
 
 
-def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None):
+def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None, route="default"):
+    """``route``: "lane" = the ego follows the centre line of its lanes in the reference's network (``scenario.py``; TraCI reports those
+    positions), None = the straight lines the planner assumes (prediction.py:46-59); "default" = ``STMPC_SIM_ROUTE`` (lane / straight), lane if unset."""
     S = Settings
-    ex, ey = ego_start_position()
+    if route == "default":
+        route = None if os.environ.get("STMPC_SIM_ROUTE", "lane") == "straight" else "lane"
+    ex, ey = ego_start_position(route)
     g = lambda name, default: getattr(S, name, default)
     return _capi.SimCfg(tick_length=S.TICK_LENGTH, other_car_speed=g("OTHER_CAR_SPEED", 7.0), base_traffic_interval=g("BASE_TRAFFIC_INTERVAL", 1.2),
                         spawn_x=SPAWN_X, despawn_x=DESPAWN_X, ego_start_x=ex, ego_start_y=ey, arrive_x=ARRIVE_X, sensor_radius=g("SENSOR_RADIUS", 125.0),
@@ -42,7 +49,8 @@ def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None):
                         veh_accel=4.5, veh_decel=6.0, veh_min_gap=1.0, veh_tau=0.5, veh_emergency_decel=9.0, veh_length=g("CAR_LENGTH", 5.0), veh_width=1.8, speed_dev=0.0,
                         vary_traffic_start_times=int(bool(g("VARY_TRAFFIC_START_TIMES", True))),
                         randomize_start_speed=int(bool(g("RANDOMIZE_START_SPEED", True))), max_ticks=int(max_episode_length / S.TICK_LENGTH),
-                        yield_overlap=int(os.environ.get("STMPC_SIM_YIELD_OVERLAP", "0")) if yield_overlap is None else int(yield_overlap), seed=int(seed))
+                        yield_overlap=int(os.environ.get("STMPC_SIM_YIELD_OVERLAP", "2")) if yield_overlap is None else int(yield_overlap),
+                        seed=int(seed), disruption_min_s=float(g("MERGE_POINT_X", -50.0))).set_route(np.stack(scenario.lane_polyline()[:2], axis=1) if route == "lane" else None)
 
 
 class EpisodeRunner:
@@ -118,6 +126,12 @@ class EpisodeRunner:
                "closest_distance": np.where(acc[:, 7] > 0, acc[:, 5], np.nan), "mean_closest_distance": np.where(acc[:, 7] > 0, acc[:, 6] / np.maximum(acc[:, 7], 1.0), np.nan),
                "time_taken": ticks * self.tick_length, "ticks": ticks, "status": status, "ego4": ego4}
         out["time_to_merge"] = np.where(status == 1, out["time_taken"], np.nan)
+        # the reference's "disruption" columns (stats.py:64-68): deceleration of the nearest vehicle behind the ego, per controlled tick past MERGE_POINT_X
+        have = acc[:, 10] > 0
+        out["mean_disruption"] = np.where(have, acc[:, 8] / np.maximum(acc[:, 10], 1.0), np.nan)
+        out["max_disruption"] = np.where(have, acc[:, 9], np.nan)
+        out["total_disruption"] = np.where(have, acc[:, 8] * self.tick_length, np.nan)
+        out["disruption_time"] = np.where(have, acc[:, 11] * self.tick_length, np.nan)
         if self.controller == "combined":
             out["percent_st"] = (self.takeovers / self.torch.clamp(self.controlled, min=1.0)).cpu().numpy()
         return out

@@ -1,19 +1,23 @@
 """batched SUMO-free merge episodes.  STATISTICAL parity, and labelled so: the world restates the SUMO scenario the
-reference configures (Krauss vehicles of its "simple traffic distribution", the ego under speed mode 22) but is not SUMO.  The test
-compares the per-episode means of the reference's pure-ST evaluation at its three traffic densities (experiment_data/saved_data.csv,
-rows st_low / st_medium / st_default, 4000-10000 SUMO episodes each) with 1024 episodes of this world, with tolerances set just above
-what is measured (time to merge +0.9 ... +2.4 %, mean speed -1.4 ... -2.9 %, mean |jerk| -1 ... -2 % in dense and
-medium traffic): every episode merges, at most 0.5 % crash (reference: none), time to merge and mean speed within 5 %, maximum speed
-within 3 %, closest distance within 6 %, mean |jerk| within 10 % at 1.8 s and 1.2 s headway.  Known gap, kept visible: mean |jerk| at
-2.4 s headway is +20 % (1.29 against 1.07); the test prints the measured deviation and fails if it grows beyond +30 % (an improvement
-passes)."""
+reference configures (Krauss vehicles of its "simple traffic distribution", the ego under speed mode 22 on the centre line of its lanes,
+highway vehicles that brake hard while the ego laps in -- DESIGN.md section 9) but is not SUMO.  The tests compare per-episode means with the
+reference's reported rows (experiment_data/saved_data.csv, 4000-10000 SUMO episodes each; numbers copied as data) on 1024 episodes of this
+world, with tolerances set just above what is measured (profiles/r5/world_rules.txt): the pure ST controller at its three traffic densities
+(time to merge +0.7 ... +1.9 %, mean speed -1.1 ... -2.4 %, mean |jerk| -1 ... -7 %, closest distance -0.3 ... -3.3 %, no crashes), and the
+combined controller with the reference's pretrained actor on BASELINE configs[2] (ST share of ticks 2.0 % against 2.4 %)."""
 import numpy as np
 import pytest
 
 # the reference's reported means for TASK "ST" (numbers copied as data: saved_data.csv rows 4, 13, 20)
-REFERENCE_ST = {2.4: dict(crashed=0.0, merged=1.0, mean_speed=10.416, max_speed=23.612, time_to_merge=25.659, mean_abs_jerk=1.074, closest_distance=10.110),
-                1.8: dict(crashed=0.0, merged=1.0, mean_speed=9.297, max_speed=23.296, time_to_merge=28.645, mean_abs_jerk=1.262, closest_distance=10.273),
-                1.2: dict(crashed=0.0, merged=1.0, mean_speed=8.919, max_speed=23.149, time_to_merge=29.838, mean_abs_jerk=1.105, closest_distance=10.153)}
+REFERENCE_ST = {2.4: dict(crashed=0.0, merged=1.0, mean_speed=10.416, max_speed=23.612, time_to_merge=25.659, mean_abs_jerk=1.074, closest_distance=10.110,
+                          max_disruption=3.222, total_disruption=2.254),
+                1.8: dict(crashed=0.0, merged=1.0, mean_speed=9.297, max_speed=23.296, time_to_merge=28.645, mean_abs_jerk=1.262, closest_distance=10.273,
+                          max_disruption=6.490, total_disruption=6.949),
+                1.2: dict(crashed=0.0, merged=1.0, mean_speed=8.919, max_speed=23.149, time_to_merge=29.838, mean_abs_jerk=1.105, closest_distance=10.153,
+                          max_disruption=6.638, total_disruption=6.902)}
+# TASK EVALUATE_COMBINED_DDPG under configs/combined_medium_1.json (BASELINE configs[2]; saved_data.csv row 15)
+REFERENCE_COMBINED_MEDIUM_1 = dict(crashed=0.0, merged=1.0, mean_speed=10.400, max_speed=18.149, time_to_merge=25.904, mean_abs_jerk=0.809, closest_distance=7.246,
+                                   percent_st=0.0238, max_disruption=6.526, total_disruption=7.313)
 
 
 @pytest.mark.gpu
@@ -29,21 +33,47 @@ def test_st_episodes_match_the_reference_statistically(interval, gpu_ctx, restor
     ref = REFERENCE_ST[interval]
     assert (st["crashed"] + st["merged"] + st["timed_out"] == 1).all()
     assert s["merged"] >= 0.995                                   # reference: 1.0
-    assert s["crashed"] <= 0.005                                  # reference: 0.0 (measured 0 / 0.0005 / 0.0015)
-    assert abs(s["time_to_merge"] - ref["time_to_merge"]) <= 0.05 * ref["time_to_merge"]
-    assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.05 * ref["mean_speed"]
+    assert s["crashed"] <= 0.002                                  # reference: 0.0 (measured 0 / 0 / 0.0005)
+    assert abs(s["time_to_merge"] - ref["time_to_merge"]) <= 0.04 * ref["time_to_merge"]
+    assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.04 * ref["mean_speed"]
     assert abs(s["max_speed"] - ref["max_speed"]) <= 0.03 * ref["max_speed"]
     jerk_dev = s["mean_abs_jerk"] / ref["mean_abs_jerk"] - 1.0
     print("headway %.1f s: mean |jerk| %.3f, %+.1f %% against the reference's %.3f" % (interval, s["mean_abs_jerk"], 100 * jerk_dev, ref["mean_abs_jerk"]))
-    if interval == 2.4:
-        assert -0.10 <= jerk_dev <= 0.30, jerk_dev                 # the known gap in light traffic (+20 %): may close, must not grow
-    else:
-        assert abs(jerk_dev) <= 0.10, jerk_dev
-    assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.06 * ref["closest_distance"]
+    assert abs(jerk_dev) <= 0.10, jerk_dev                         # (rounds 3-4: +20 % in light traffic -- the ego then moved on a chord of the ramp)
+    assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.05 * ref["closest_distance"]
+    # the reference's "disruption" columns (deceleration of the vehicle behind the ego): the junction rule is chosen on them
+    assert abs(s["max_disruption"] - ref["max_disruption"]) <= 0.25 * ref["max_disruption"]
+    assert 0.6 * ref["total_disruption"] <= s["total_disruption"] <= 1.2 * ref["total_disruption"]
     if interval == 2.4:
         # determinism: same seed, same episodes
         st2 = episodes.run_episodes(n, seed=7, controller="st", ctx=gpu_ctx)
         assert np.array_equal(st["ticks"], st2["ticks"]) and np.array_equal(st["mean_speed"], st2["mean_speed"])
+
+
+@pytest.mark.gpu
+def test_combined_episodes_match_the_reference_statistically(gpu_ctx, restore_settings):
+    """BASELINE configs[2] end to end: 1024 episodes under the combined controller with the reference's ddpg_medium1 actor (restated
+    TimeFeature input, five evaluations per tick) against the reference's own report for that config."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import actor, combined_bench, episodes
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1)
+    pkg.apply_overrides(combined_bench.COMBINED_MEDIUM_1_TRAFFIC)
+    n = 1024
+    policy = actor.DDPGActor("runs/ddpg_medium1_extended", n, gpu_ctx, pkg.Settings, torch.device("cuda", torch.cuda.current_device()))
+    st = episodes.run_episodes(n, seed=21, controller="combined", policy=policy, ctx=gpu_ctx, kmax=16)
+    s, ref = episodes.summary(st), REFERENCE_COMBINED_MEDIUM_1
+    print({k: round(v, 4) for k, v in s.items()})
+    assert s["merged"] >= 0.995 and s["crashed"] <= 0.003          # measured 1.0 / 0.0
+    assert abs(s["time_to_merge"] - ref["time_to_merge"]) <= 0.04 * ref["time_to_merge"]          # measured +2.0 %
+    assert abs(s["mean_speed"] - ref["mean_speed"]) <= 0.05 * ref["mean_speed"]                   # -2.8 %
+    assert abs(s["max_speed"] - ref["max_speed"]) <= 0.03 * ref["max_speed"]                      # -1.2 %
+    assert abs(s["mean_abs_jerk"] - ref["mean_abs_jerk"]) <= 0.10 * ref["mean_abs_jerk"]          # +5.6 %
+    assert abs(s["closest_distance"] - ref["closest_distance"]) <= 0.05 * ref["closest_distance"]  # +1.5 %
+    assert 0.012 <= s["percent_st"] <= 0.036                       # the reference's 2.4 % of ticks; measured 2.0 %
+    assert abs(s["max_disruption"] - ref["max_disruption"]) <= 0.15 * ref["max_disruption"]       # +4 %
+    assert abs(s["total_disruption"] - ref["total_disruption"]) <= 0.20 * ref["total_disruption"]  # +9 %
 
 
 @pytest.mark.gpu

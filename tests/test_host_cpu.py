@@ -53,8 +53,12 @@ def _header_struct_fields(name):
         stmt = " ".join(stmt.split())
         if not stmt:
             continue
+        if stmt.startswith("const "):
+            stmt = stmt[6:]
         ctype, rest = stmt.split(" ", 1)
-        out += [(n.strip(), ctype) for n in rest.split(",")]
+        for n in rest.split(","):
+            n = n.strip()
+            out.append((n.lstrip("*"), ctype + " *" if n.startswith("*") else ctype))
     return out
 
 
@@ -62,7 +66,8 @@ def test_every_other_struct_layout_matches_header():
     """stmpc_stats, stmpc_combined_cfg, stmpc_policy_features_cfg, stmpc_sim_cfg, stmpc_profile_totals: the ctypes mirrors have the header's
     fields in the header's order with the header's types (a field added on one side only would shift everything after it silently)."""
     capi = _lib()
-    ctype_of = {"double": ctypes.c_double, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64}
+    ctype_of = {"double": ctypes.c_double, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+                "double *": ctypes.POINTER(ctypes.c_double)}
     for name, cls in (("stmpc_stats", capi.Stats), ("stmpc_combined_cfg", capi.CombinedCfg), ("stmpc_policy_features_cfg", capi.FeaturesCfg),
                       ("stmpc_sim_cfg", capi.SimCfg), ("stmpc_profile_totals", capi.ProfileTotals)):
         want = _header_struct_fields(name)
