@@ -100,3 +100,71 @@ def test_combined_controller_environments_config5_demo(gpu_ctx, restore_settings
     assert ((a["percent_st"] >= 0) & (a["percent_st"] <= 1)).all()
     assert (a["ego4"][:, 0] > episodes.ego_start_position()[0]).all()              # every ego moved
     assert np.isnan(a["time_to_merge"][a["status"] != 1]).all()
+
+
+def test_scenario_geometry_is_the_networks():
+    """``scenario.py`` holds lane ramp_0 and the junction's internal lane as merge.net.xml states them: lengths 201.92 / 52.18 m
+    (merge.net.xml:52,42), x strictly increasing, and the ego's departure point 40 m along the ramp."""
+    from rl_mpc_lanemerging_amd import episodes, scenario
+    x, y, arc = scenario.lane_polyline()
+    assert len(x) == 105 and (np.diff(x) > 0).all()
+    assert abs(arc[-2] - 201.92) < 0.02 and abs((arc[-1] - arc[-2]) - 52.18) < 0.01
+    assert (x[0], y[0]) == (-250.47, 28.47) and (x[-2], y[-2]) == scenario.JUNCTION_ENTRY and (x[-1], y[-1]) == scenario.JUNCTION_EXIT
+    px, py = scenario.point_at_arc(40.0)
+    i = np.searchsorted(x, px)
+    assert abs(np.interp(px, x, y) - py) < 1e-9 and abs(arc[i - 1] + np.hypot(px - x[i - 1], py - y[i - 1]) - 40.0) < 1e-9
+    assert scenario.point_at_arc(arc[-1] + 10.0) == (x[-1] + 10.0, scenario.HIGHWAY_LANE_Y)
+    assert episodes.ego_start_position("lane") == (px, py)
+    cfg = episodes.sim_cfg(1, route="lane")
+    assert cfg.ego_route_n == 105 and cfg.ego_route_xy[0] == -250.47 and cfg.ego_route_xy[2 * 104 + 1] == -1.6
+    assert episodes.sim_cfg(1, route=None).ego_route_n == 0
+
+
+@pytest.mark.gpu
+def test_the_ego_stays_on_its_lane_and_covers_what_it_is_told(gpu_ctx, restore_settings):
+    """World mechanics: with a route the ego's positions lie on the polyline, every tick advances it by the commanded speed x tick along it
+    (within the acceleration limits), beyond the junction exit it runs on at y = -1.6; a route whose x is not increasing is refused."""
+    import torch
+    import rl_mpc_lanemerging_amd as pkg
+    from rl_mpc_lanemerging_amd import _capi, episodes, scenario
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    n = 64
+    cfg = episodes.sim_cfg(5, route="lane")
+    params = _capi.Params.from_settings(pkg.Settings)
+    gpu_ctx.sim_init(cfg, n)
+    x, y, arc = scenario.lane_polyline()
+
+    def arc_of(px, py):
+        out = np.empty(len(px))
+        for q, (a, b) in enumerate(zip(px, py)):
+            if a >= x[-1]:
+                assert b == -1.6
+                out[q] = arc[-1] + (a - x[-1])
+                continue
+            i = min(max(np.searchsorted(x, a, side="right"), 1), len(x) - 1)
+            t = (a - x[i - 1]) / (x[i] - x[i - 1])
+            assert abs(y[i - 1] + t * (y[i] - y[i - 1]) - b) < 1e-9, (a, b)           # on the segment
+            out[q] = arc[i - 1] + np.hypot(a - x[i - 1], b - y[i - 1])
+        return out
+    _, _, _, ego = gpu_ctx.sim_read(n)
+    assert np.allclose(arc_of(ego[:, 0], ego[:, 1]), 40.0, atol=1e-9)
+    cmd = torch.full((n,), 12.0, dtype=torch.float64, device="cuda")
+    dt = pkg.Settings.TICK_LENGTH
+    for tick in range(150):
+        status0, _, _, before = gpu_ctx.sim_read(n)
+        gpu_ctx.sim_step(params, cfg, n, cmd.data_ptr())
+        _, _, _, after = gpu_ctx.sim_read(n)
+        run = status0 == 0
+        v = after[run, 2]
+        lo, hi = before[run, 2] + pkg.Settings.MAX_NEGATIVE_ACCELERATION * dt, before[run, 2] + pkg.Settings.MAX_POSITIVE_ACCELERATION * dt
+        assert np.allclose(v, np.clip(12.0, lo, hi), atol=1e-12)
+        assert np.allclose(arc_of(after[run, 0], after[run, 1]) - arc_of(before[run, 0], before[run, 1]), v * dt, atol=1e-9)
+        assert np.array_equal(after[~run], before[~run])                              # finished environments idle
+    assert (gpu_ctx.sim_read(n)[0] != 0).all()                                        # 12 m/s for 30 s: everybody arrived or collided
+    bad = episodes.sim_cfg(5, route="lane")
+    xy = np.stack([x, y], axis=1)
+    xy[10, 0] = xy[9, 0]
+    bad.set_route(xy)
+    with pytest.raises(_capi.StmpcError):
+        gpu_ctx.sim_init(bad, n)
+    gpu_ctx.sim_init(cfg, n)                                                          # (leave the shared context with a valid world)
