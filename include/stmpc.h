@@ -428,8 +428,10 @@ typedef struct stmpc_sim_cfg {
                                         front -- the ego "laps in": 0 = nothing until the lanes are less than a vehicle width apart; 1 = it follows the ego at once
                                         (Krauss with a negative gap: brakes for a slow ego, not for a fast one); 2 = SUMO's link-leader rule as its effect shows in the
                                         reference's "disruption" columns: a vehicle whose front is behind the ego's front is asked to STOP while the ego laps in
-                                        (emergency braking, whatever the ego's speed); 3 = as 2 for every vehicle that overlaps the ego at all.  The package's
-                                        default is 2 (DESIGN.md section 9 compares the four) */
+                                        (emergency braking, whatever the ego's speed); 3 = as 2 for every vehicle that overlaps the ego at all; 4 = as 2, and a vehicle that
+                                        overlaps the ego with its front still ahead stops too if the ego is the faster of the two and the vehicle has not reached the
+                                        point where the lanes begin to overlap (x = -37.8; SUMO breaks the tie of two vehicles on a junction by speed).  The
+                                        package's default is 2 (DESIGN.md section 9 compares them) */
     uint64_t seed;
     const double *ego_route_xy;      /* HOST [ego_route_n][2]: polyline of the ego's lane centre line from the ramp's start to the junction exit, x strictly
                                         increasing (beyond its last point the ego keeps that point's y); read by stmpc_sim_init_device, which keeps a device

@@ -444,11 +444,13 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
             // behind an ego that cuts in brakes at its EMERGENCY deceleration for ~3 ticks however fast the ego is; MSVehicle::getSafeFollowSpeed's
             // branch for a negative gap asks for a stop, not for a follow speed): with room behind the ego's rear (net of minGap) the vehicle
             // follows it like any leader; while the ego laps in, a vehicle whose front is behind the ego's front (rule 2) -- or that overlaps
-            // the ego at all (rule 3) -- is asked to stop, i.e. brakes as hard as it can until the ego's rear is clear
+            // the ego at all (rule 3), or overlaps it, is the slower of the two and has not reached the lanes' overlap at x = -37.8 (rule 4) --
+            // is asked to stop, i.e. brakes as hard as it can until the ego's rear is clear
             const double g_net = ego_pos0 - c.veh_length - ox_ - c.veh_min_gap;
             double vs = __builtin_inf();
             if (g_net >= 0.0) vs = krauss_follow(c, g_net, v_prev);
-            else if (ego_pos0 > ox_ || (c.yield_overlap == 3 && ego_pos0 > ox_ - c.veh_length)) vs = 0.0;
+            else if (ego_pos0 > ox_ || (c.yield_overlap == 3 && ego_pos0 > ox_ - c.veh_length) ||
+                     (c.yield_overlap == 4 && ego_pos0 > ox_ - c.veh_length && v_prev > ov_ && ox_ < -37.8)) vs = 0.0;
             vnext = vs < vnext ? vs : vnext;
         } else if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
             const double vs = krauss_follow(c, ego_pos0 - c.veh_length - ox_ - c.veh_min_gap, v_prev);
@@ -502,8 +504,9 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
         a[8] += dis; a[9] = dis > a[9] ? dis : a[9]; a[10] += 1.0; if (dis != 0.0) a[11] += 1.0;
     }
     s.ticks[e] = tk + 1;
-    if (crashed) s.status[e] = 2;
-    else if (px >= c.arrive_x) s.status[e] = 1;
+    // (a vehicle that reaches its arrival position leaves SUMO's network inside the move, before the step's collision check sees it)
+    if (px >= c.arrive_x) s.status[e] = 1;
+    else if (crashed) s.status[e] = 2;
     else if (tk + 1 >= c.max_ticks) s.status[e] = 3;
 }
 }  // namespace sim

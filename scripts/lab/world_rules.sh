@@ -10,8 +10,8 @@ for line in sys.stdin:
     for k in ("here","reference"):
         print(name.ljust(24),k.ljust(10)," ".join("%s %.3f"%(a[:16],b) for a,b in d[k].items()))
 '
-for cfg in "lane 2" "lane 3" "lane 1" "lane 0" "straight 0"; do
-  set -- $cfg
+for cfg in $(echo ${WORLD_CFGS:-lane:2,lane:3,lane:4,lane:1,lane:0,straight:0} | tr ',' ' '); do
+  set -- ${cfg%%:*} ${cfg##*:}
   echo "== ego route $1, junction rule $2"
   STMPC_SIM_ROUTE=$1 STMPC_SIM_YIELD_OVERLAP=$2 python scripts/lab/crash_probe.py 2048 2>&1 | grep -A1 "^interval" | grep -v "^--" | cut -c1-560
   STMPC_SIM_ROUTE=$1 STMPC_SIM_YIELD_OVERLAP=$2 python scripts/lab/combined_episodes.py 1024 2>&1 | grep -v amdgpu.ids | python -c "$fmt"
