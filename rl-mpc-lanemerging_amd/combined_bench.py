@@ -97,6 +97,7 @@ def run(args, rank, world, dev, dist):
            "actor_on_pytorch_rocm": {"value": n * world * args.steps / elapsed_torch, "unit": "ticks/s", "ms_per_step": elapsed_torch / args.steps * 1e3,
                                      "note": "same tick with the network as three rocBLAS GEMMs + elementwise kernels on PyTorch-ROCm (inputs from k_policy_features)",
                                      "decisions_that_differ_from_the_fused_kernel": same_decisions},
+           "library": {"backend": _capi.backend_info()},
            "decisions": {"policy_kept": int((reason == 0).sum()), "crash_predicted": int((reason == 1).sum()), "too_fast": int((reason == 2).sum()),
                          "probe_rejected": int((reason == 3).sum()), "st_better": int((reason == 4).sum())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

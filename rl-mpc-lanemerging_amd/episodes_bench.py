@@ -53,7 +53,8 @@ def run(args, rank, world, dev, dist):
     return {"metric": "environment steps/sec of batched merge episodes under the combined RL+MPC controller (configs/train_moderate_1.json traffic; throughput demo)",
             "value": n * world * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "reference_counterpart": False,
+            "reference_counterpart": False, "library": {"backend": _capi.backend_info()},
+            "world": {"ego_route": "lane centre line (scenario.py)" if r.cfg.ego_route_n else "straight lines", "junction_rule": int(r.cfg.yield_overlap)},
             "config": {"workload": "N=%d environments/GPU in lock-step, every tick: planner view, %d-step policy rollout (pretrained ddpg_moderate1 actor), feasibility "
                                    "probe solve, controller solve (H=%d, S=%d) + QP re-sampling, decision, world step (Krauss traffic %.1f s / %.0f m/s)"
                                    % (n, max(int(S.ROLLOUT_LENGTH), 1), _capi.num_t(r.params), _capi.num_s(r.params, 0.0), S.BASE_TRAFFIC_INTERVAL, S.OTHER_CAR_SPEED),
