@@ -42,7 +42,11 @@ int astar_table(double ds, double dt, int H, double v_w, double a_w, double j_w,
     return 0;
 }
 
-typedef struct { long long nodes, edges, edges_filt, cut_h, reached; int best_t; double cost; int pruned; long long span_sum, layers; } astar_out;
+typedef struct { long long nodes, edges, edges_filt, cut_h, reached; int best_t; double cost; int pruned; long long span_sum, layers;
+                 int first_cut_layer; long long nodes_before_cut; } astar_out;
+/* retry study (oracle/analysis/retry_depth.py): a pass under the bound U and one under U2 > U are the same up to the first layer that holds a node with
+ * U < cost <= U2 -- the failed pass dropped it, the retry expands it.  astar_U2 > 0: record that layer and the nodes expanded before it. */
+double astar_U2 = 0.0;
 
 /* Bounded layered pass (orc_solve_layered with "expand only nodes <= U"), optionally with the cost-to-go test.
  * use_h: 0 plain bound, 1 + cost-to-go at expansion.  deflate: factor (< 1) on F against the rounding of the lattice. */
@@ -64,6 +68,7 @@ int astar_pass(const uint8_t *obstacles, const double *s_values, int S, const do
     cur_c[0] = 0.0; cur_p1[0] = -1; cur_p2[0] = -2;
     int lo_w = 0, hi_w = 1, best_t = 0, best_s = 0; double best_cost = 0.0;
     memset(out, 0, sizeof *out);
+    out->first_cut_layer = -1;
     const double Kq = v_w / (delta_t * delta_t) + a_w / (delta_t * delta_t * delta_t * delta_t) + j_w / (dt3 * dt3);
     for (int t = 0; t < H - 1; t++) {
         int nlo = S, nhi = 0;
@@ -75,7 +80,11 @@ int astar_pass(const uint8_t *obstacles, const double *s_values, int S, const do
             double C = cur_c[s];
             if (!(C < INFINITY)) continue;
             out->reached++;
-            if (C > U) { out->pruned = 1; continue; }
+            if (C > U) {
+                out->pruned = 1;
+                if (astar_U2 > 0.0 && C <= astar_U2 && out->first_cut_layer < 0) { out->first_cut_layer = t; out->nodes_before_cut = out->nodes; }
+                continue;
+            }
             const double sv = s_values[s];
             const double h1 = cur_p1[s] == -1 ? est_prev : s_values[cur_p1[s]];
             const double h2 = cur_p2[s] == -2 ? est_second : (cur_p2[s] == -1 ? est_prev : s_values[cur_p2[s]]);

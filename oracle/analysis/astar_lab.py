@@ -22,7 +22,8 @@ L = C.CDLL(so)
 
 class Out(C.Structure):
     _fields_ = [("nodes", C.c_longlong), ("edges", C.c_longlong), ("edges_filt", C.c_longlong), ("cut_h", C.c_longlong), ("reached", C.c_longlong),
-                ("best_t", C.c_int), ("cost", C.c_double), ("pruned", C.c_int)]
+                ("best_t", C.c_int), ("cost", C.c_double), ("pruned", C.c_int), ("span_sum", C.c_longlong), ("layers", C.c_longlong),
+                ("first_cut_layer", C.c_int), ("nodes_before_cut", C.c_longlong)]
 
 
 dp = C.POINTER(C.c_double)
