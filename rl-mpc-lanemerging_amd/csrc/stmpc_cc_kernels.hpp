@@ -326,8 +326,8 @@ __device__ __forceinline__ double krauss_follow(const Cfg &c, double gap, double
     return safe_stop_speed(gap + brake_gap(lead_speed, c.veh_decel, c.tick), c.veh_decel, c.veh_tau, c.tick);
 }
 // position of the ego along the highway lane once it is on the junction's internal lane: both internal lanes start at x = -50.6, are 52.2 m long and
-// end at x = 1.5, and the ego moves on the planner's straight line (prediction.py:46-59), whose x extent differs from its length by 0.3 %: the
-// x coordinate itself, which is also what the planner compares with the vehicles' (prediction.py:78)
+// end at x = 1.5, and the ego's lane differs in x extent from its length by 0.2 %: the x coordinate itself, which is also what the planner
+// compares with the vehicles' (prediction.py:78)
 __device__ __forceinline__ double ego_lane_pos(double x, double /*y*/) { return x; }
 __global__ void __launch_bounds__(64) k_sim_init(Cfg c, int N, State s) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,9 +436,7 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
             const double vs = krauss_follow(c, lead_x - c.veh_length - ox_ - c.veh_min_gap, lead_v);
             vnext = vs < vnext ? vs : vnext;
         }
-        // the ego is a leader too (it may be closer than the vehicle ahead) once its rear is ahead of this vehicle's front -- or, if the two
-        // overlap along the lane, once the converging lanes are less than a vehicle width apart there (SUMO's sublane junction model: a foe
-        // that is laterally clear is beside the vehicle, not in front of it)
+        // the ego is a leader too (it may be closer than the vehicle ahead) once it is on the junction: Cfg::yield_overlap says from when on
         if (ego_on_lane && c.yield_overlap >= 2) {
             // SUMO's link leader on merging internal lanes, restated from its observable effect (the reference's "disruption" columns: the vehicle
             // behind an ego that cuts in brakes at its EMERGENCY deceleration for ~3 ticks however fast the ego is; MSVehicle::getSafeFollowSpeed's
@@ -453,6 +451,8 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
                      (c.yield_overlap == 4 && ego_pos0 > ox_ - c.veh_length && v_prev > ov_ && ox_ < -37.8)) vs = 0.0;
             vnext = vs < vnext ? vs : vnext;
         } else if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
+            // rules 0 / 1 (rounds 3-4): an ordinary Krauss follow once the ego's rear is ahead of this vehicle's front -- or, if the two overlap
+            // along the lane, at once (rule 1) / once the converging lanes are less than a vehicle width apart there (rule 0)
             const double vs = krauss_follow(c, ego_pos0 - c.veh_length - ox_ - c.veh_min_gap, v_prev);
             vnext = vs < vnext ? vs : vnext;
         }
