@@ -79,7 +79,10 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
     unsigned *HM = RGl + (MSW + CL_THREADS);
     unsigned round = 0;                                    // barriers passed (thread 0)
 #ifdef STMPC_CL_DEBUG
-    unsigned long long dbg_bar = 0, dbg_ep = 0, dbg_t0 = 0, dbg_first = 0, dbg_last = 0; int dbg_n = 0;
+    unsigned long long dbg_bar = 0, dbg_ep = 0, dbg_t0 = 0, dbg_first = 0, dbg_last = 0, dbg_ph[6] = {0, 0, 0, 0, 0, 0}, dbg_tp = 0; int dbg_n = 0;
+#define CLPH(k) do { if (m == 0 && tid == 0) { const unsigned long long t_ = wall_clock64(); dbg_ph[k] += t_ - dbg_tp; dbg_tp = t_; } } while (0)
+#else
+#define CLPH(k) do { } while (0)
 #endif
     const double dt = p.dt, dt2 = p.dt2, dt3 = p.dt3;
     const double zl_dt = a.zl_dt, zl_dt2 = a.zl_dt2, zl_dt3 = a.zl_dt3;
@@ -158,8 +161,8 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
         const int e = __builtin_amdgcn_readfirstlane(ldi(&ctl->ep));
 #ifdef STMPC_CL_DEBUG
         if (e < 0 && m == 0 && tid == 0 && dbg_n)
-            printf("cluster %2d: %d episodes, %.0f us in them, %.0f us of that in barriers (leader thread 0); first began %.0f us after the kernel did, last ended at %.0f us\n", cl, dbg_n,
-                   dbg_ep * 0.01, dbg_bar * 0.01, (dbg_first - t_begin) * 0.01, (dbg_last - t_begin) * 0.01);
+            printf("cluster %2d: %d episodes, %.0f us in them, %.0f us of that in barriers; staging %.0f masks %.0f cells %.0f fold %.0f barrier %.0f totals %.0f\n", cl, dbg_n,
+                   dbg_ep * 0.01, dbg_bar * 0.01, dbg_ph[0] * 0.01, dbg_ph[1] * 0.01, dbg_ph[2] * 0.01, dbg_ph[3] * 0.01, dbg_ph[4] * 0.01, dbg_ph[5] * 0.01);
         if (m == 0 && tid == 0) { dbg_t0 = wall_clock64(); if (!dbg_first) dbg_first = dbg_t0; }
 #endif
         if (e < 0) return;
@@ -239,9 +242,16 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
                 const u64 wb = wave_min_u64(my_best);
                 const int wbn = wave_min_i(my_best == wb ? my_best_n : 0x7fffffff);
                 if (lane == 0) { sh_best[wave] = wb; sh_bestn[wave] = wbn; }
-                if (acc_nodes) atomicAdd(&sh_i[1], acc_nodes);
-                if (acc_hi > acc_lo) { atomicMin(&sh_i[2], acc_lo); atomicMax(&sh_i[3], acc_hi); }
-                if (acc_pruned) atomicOr(&sh_i[4], 1);
+                // (one LDS atomic per WAVE: hundreds of lanes on one address serialise)
+                int wn = acc_nodes;
+                for (int off = 1; off < 64; off <<= 1) wn += __shfl_xor(wn, off);
+                const int wlo_ = wave_min_i(acc_hi > acc_lo ? acc_lo : 0x7fffffff), whi_ = wave_max_i(acc_hi > acc_lo ? acc_hi : 0);
+                const bool wpr = __ballot(acc_pruned) != 0ull;
+                if (lane == 0) {
+                    if (wn) atomicAdd(&sh_i[1], wn);
+                    if (whi_ > wlo_) { atomicMin(&sh_i[2], wlo_); atomicMax(&sh_i[3], whi_); }
+                    if (wpr) atomicOr(&sh_i[4], 1);
+                }
                 __syncthreads();
                 if (tid == 0) {
                     ClusterLayer *L = LS + tt;
@@ -302,26 +312,35 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
                     const u64 *Cs = Cg + (size_t)(t & 1) * SP; const unsigned *HKs = HKg + (size_t)(t & 1) * SP, *RGs = RGg + (size_t)(t & 1) * SP;
                     u64 *Cd = Cg + (size_t)((t + 1) & 1) * SP; unsigned *HKd = HKg + (size_t)((t + 1) & 1) * SP, *RGd = RGg + (size_t)((t + 1) & 1) * SP;
                     const int t64 = tlo & ~63;
-                    for (int base = t64 + m * CL_THREADS; base < thi; base += G * CL_THREADS) {
-                        // sources this workgroup's cells [base, base + 512) can be reached from: [base - MSW, base + 512) within the layer's span
+                    // lanes per cell: a layer narrower than the cluster spreads the offers of a cell over 2 or 4 adjacent lanes (each walks the
+                    // cell's mask and takes every LPC-th offer; the group's minimum by (cost, source) follows) -- the offers of a cell are a
+                    // dependent fp64 chain, and in a bounded layer most lanes would idle
+                    const int span = thi - t64;
+                    const int lsh = (span * 4 <= G * CL_THREADS) ? 2 : ((span * 2 <= G * CL_THREADS) ? 1 : 0);
+                    const int LPC = 1 << lsh, cpb = CL_THREADS >> lsh;            // cells per workgroup and pass
+                    const int cell = tid >> lsh, sub = tid & (LPC - 1);
+                    for (int base = t64 + m * cpb; base < thi; base += G * cpb) {
+                        // sources this workgroup's cells [base, base + cpb) can be reached from: [base - MSW, base + cpb) within the layer's span
                         const int w0 = base - MSW;
                         __syncthreads();
-                        for (int x = tid; x < MSW + CL_THREADS; x += CL_THREADS) {
+                        CLPH(5);
+                        for (int x = tid; x < MSW + cpb; x += CL_THREADS) {
                             const int i = w0 + x;
                             const bool in = i >= slo && i < shi;
                             Cl[x] = in ? Cs[i] : INF_BITS;
                             HKl[x] = in ? HKs[i] : 0u;
                             RGl[x] = in ? RGs[i] : 0u;
                         }
-                        for (int w = 0; w < NWD; ++w) HM[tid * NWD + w] = 0u;
+                        for (int w = tid; w < cpb * NWD; w += CL_THREADS) HM[w] = 0u;
                         __syncthreads();
+                        CLPH(0);
                         // which sources offer which cell: every source marks itself in the masks of the cells of its range (bit = its
                         // distance from the low end of the cell's window, so ascending bits are ascending sources)
-                        for (int x = tid; x < MSW + CL_THREADS; x += CL_THREADS) {
+                        for (int x = tid; x < MSW + cpb; x += CL_THREADS) {
                             const unsigned rg = RGl[x];
                             int lo = (int)(rg & 0xFFFFu), hi = (int)(rg >> 16);
                             if (lo < base) lo = base;
-                            if (hi > base + CL_THREADS) hi = base + CL_THREADS;
+                            if (hi > base + cpb) hi = base + cpb;
                             const int i = w0 + x;
                             for (int n = lo; n < hi; ++n) {
                                 const int bit = i - n + MSW;                        // in [0, MSW]: i <= n <= i + maxshift
@@ -329,8 +348,11 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
                             }
                         }
                         __syncthreads();
-                        const int n = base + tid;
-                        if (n >= tlo && n < thi) {
+                        CLPH(1);
+                        const int n = base + cell;
+                        const bool mine = n >= tlo && n < thi;
+                        u64 bestv = INF_BITS; unsigned bestkey = 0u;
+                        if (mine) {
                             // penalty of cell n in layer t + 1 (dp_pass::cell_penalty, table form)
                             const double sn = sval(n);
                             double d = 1e10;                                         // st.py:34-35
@@ -340,15 +362,16 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
                                 d = __builtin_fmin(d, fabs(sn - cedge[c * 2 + 1]));
                                 blocked |= (n >= cwin[c * 2 + 0]) & (n < cwin[c * 2 + 1]);
                             }
-                            u64 bestv = INF_BITS; unsigned bestkey = 0u;
                             if (!blocked) {
                                 const double pn = dev_weighted_penalty(d, p.min_allowed, p.d_w);
+                                int k = 0;
                                 for (int w = 0; w < NWD; ++w) {
-                                    unsigned mw = HM[tid * NWD + w];
+                                    unsigned mw = HM[cell * NWD + w];
                                     while (mw) {
                                         const int b = __builtin_ctz(mw);
                                         mw &= mw - 1u;
-                                        const int x = tid + w * 32 + b, i = w0 + x;     // source i = (n - MSW) + bit
+                                        if (((k++) & (LPC - 1)) != sub) continue;
+                                        const int x = cell + w * 32 + b, i = w0 + x;    // source i = (n - MSW) + bit
                                         const u64 cb = Cl[x];
                                         const unsigned h = HKl[x];
                                         const double C = __longlong_as_double((long long)cb);
@@ -373,13 +396,25 @@ __global__ void __launch_bounds__(CL_THREADS, 4) k_cluster(SolveArgs a, ClusterA
                                     }
                                 }
                             }
+                        }
+                        // the group's minimum: cost first, then the smaller source (the key's high half) -- the reference's heap order
+                        for (int off = 1; off < LPC; off <<= 1) {
+                            const unsigned olo = __shfl_xor((unsigned)bestv, off), ohi = __shfl_xor((unsigned)(bestv >> 32), off);
+                            const unsigned okey = __shfl_xor(bestkey, off);
+                            const u64 ov = ((u64)ohi << 32) | olo;
+                            if (ov < bestv || (ov == bestv && okey < bestkey)) { bestv = ov; bestkey = okey; }
+                        }
+                        if (mine && sub == 0) {
                             const unsigned rgn = as_source(t + 1, n, bestv, bestkey, acc_nodes, acc_lo, acc_hi, acc_pruned, mb, mbn);
                             Cd[n] = bestv; HKd[n] = bestkey; RGd[n] = rgn;
                         }
                     }
                 }
+                CLPH(2);
                 fold(t + 1, acc_nodes, acc_lo, acc_hi, acc_pruned, mb, mbn);
+                CLPH(3);
                 if (!cbar()) return;
+                CLPH(4);
                 slo = tlo; shi = thi;
                 int nn; u64 bb; int bn;
                 totals(t + 1, nn, tlo, thi, bb, bn);
