@@ -1074,6 +1074,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             for (int n = from + tid; n < to; n += per) {
                 st_pen(n, cell_penalty(n));
                 M::st64(&cost[n & WM], INF_BITS);
+                if constexpr (MODE == PASS_EXACT) M::st32(&hist[n & WM], 0xFFFFFFFFu);      // (above every key: see the merged winner stage)
             }
             note_written(from, to);
         };
@@ -1433,6 +1434,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 STMPC_PH(8);
             } else {
             const double two_sv = 2 * sv, three_sv = 3 * sv, three_p1 = 3 * p1;
+            const bool one_batch = (MODE == PASS_EXACT) && (fan <= (FANMAX << gsh));      // (workgroup-uniform: both forms of a batch have their own barriers)
             for (int cbase = 0; (cbase << gsh) < fan; cbase += FANMAX) {
                 // A batch whose candidate cells do not wrap around the circular arrays (and whose lanes own one source each) addresses them as
                 // one base per array plus the slot number -- immediate offsets of the LDS instructions -- instead of (cell & mask) * size per
@@ -1480,11 +1482,16 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             STMPC_PH_CAND(ok);
                             if constexpr (MODE == PASS_BOUND) { if (tb[ub + u] < my_min_tot) my_min_tot = tb[ub + u]; }
                         }
+                        if (one_batch) {
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const u64 old = M::min64(cost_at(ub + u), tb[ub + u]);
-                            if (old > tb[ub + u]) improved |= 1u << (ub + u);
-                            else if (old == tb[ub + u]) tied |= 1u << (ub + u);
+                            for (int u = 0; u < UB; ++u) (void)M::min64(cost_at(ub + u), tb[ub + u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                const u64 old = M::min64(cost_at(ub + u), tb[ub + u]);
+                                if (old > tb[ub + u]) improved |= 1u << (ub + u);
+                                else if (old == tb[ub + u]) tied |= 1u << (ub + u);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -1493,6 +1500,28 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 }
                 STMPC_BARW(3);    // B3: every min of this round is in
                 STMPC_PH(8);            // 8: stage A (candidate costs, atomic minima) + B3
+                if (one_batch) {
+                    // Winner stage of a round whose candidates all sit in ONE batch (the common case: the filter leaves 7 of a source's 21): every
+                    // candidate that equals the cell's value after B3 offers its key to ds_min_u32 -- no first-setter stage, no barrier before the
+                    // tie stage, no results of the cost atomics.  Why a minimum suffices: the rounds of a layer take its sources in DESCENDING order
+                    // and the key's high half is the source cell, so whatever an earlier round left in hist[] (or the initial ~0) is above every key
+                    // of this round; whether this round lowered the cell or only met its value, the smallest key among its equal offers is the
+                    // reference's (cost, predecessor) winner (st_cy.pyx:388).  (Not so across the batches of one round -- a later batch may lower a
+                    // cell with a LARGER source than an earlier batch's winner -- hence the staged form below for those.)
+#pragma unroll
+                    for (int ub = 0; ub < FANMAX; ub += 4) {
+                        if (__ballot(cand(cbase + ub) < hi)) {
+                            u64 cur[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (ub + u < FANMAX) cur[u] = M::ld64(cost_at(ub + u));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (ub + u < FANMAX) { if (cur[u] == tb[ub + u]) M::min32(hist_at(ub + u), key); }
+                        }
+                    }
+                    STMPC_PH(9);
+                    return;
+                }
                 // stage B: the unique first setter of a cell's final value records the predecessor.
                 // Read-backs are issued in groups of 4 (unconditionally) so their LDS latencies overlap.
 #pragma unroll
