@@ -27,7 +27,7 @@ typedef struct {
                           flat30: 64-lane groups x slots with at least one such offer; tspan_over: all such groups) */
 } lab_cfg;
 
-typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; double lay_kmin[64], lay_band[64], watch_c[64]; int watch_sel[64]; } lab_out;
+typedef struct { long long nodes, edges, maxspan, maxlayer, rounds64, flat3, flat10, flat30, tspan, tspan_over; int best_t; double cost; int complete; long long per_layer[64]; double lay_kmin[64], lay_band[64], watch_c[64]; int watch_sel[64]; long long per_layer_span[64]; long long per_layer_off[64]; } lab_out;
 static __thread const int *lab_watch = 0;   /* optional: cells of a path to watch (set through lab_set_watch) */
 void lab_set_watch(const int *w) { lab_watch = w; }
 
@@ -153,6 +153,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
         if (cnt > maxlayer) maxlayer = cnt;
         rounds64 += (cnt + 63) / 64;
         out->per_layer[t] = cnt;
+        out->per_layer_span[t] = ents[cnt - 1].s - ents[0].s + 1;   /* extent of the expanded cells (ents ascending in s unless a beam re-sorted them) */
         for (int i = lo_w > 0 ? lo_w : 0; i < S; i++) nxt_c[i] = INFINITY;
         int32_t *prev_n = previous + (size_t)(t + 1) * S;
         const int last = (t + 1 == H - 1);
@@ -171,6 +172,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
             }
             if (thi - tlo > out->tspan) out->tspan = thi - tlo;
         }
+        int off_lo = S, off_hi = 0;   /* extent of the candidates offered to layer t+1 (after the quadratic filter, blocked cells included) */
         if (cfg->gpu_round > 0) {
             const int R = cfg->gpu_round;
             double *snap = (double *)malloc(sizeof(double) * S);
@@ -241,6 +243,8 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
                     double q_ = v_w * (v - v_des) * (v - v_des) + a_w * a * a + j_w * j * j;
                     if (C + q_ > U) continue;
                 }
+                if (n < off_lo) off_lo = n;
+                if (n + 1 > off_hi) off_hi = n + 1;
                 double c = C + orc_cost_with_jerk(s_values[n], sv, cur_p1[s], cur_p2[s], delta_t, dt3, distances[nat], min_allowed, v_w, v_des, a_w, j_w, d_w);
                 edges++;
                 if (c < nxt_c[n]) {
@@ -250,6 +254,7 @@ int lab_pass(const lab_cfg *cfg, const uint8_t *obstacles, const double *s_value
                 }
             }
         }
+        if (cfg->gpu_round <= 0 && t + 1 < 64) out->per_layer_off[t + 1] = off_hi > off_lo ? off_hi - off_lo : 0;
         if (nlo >= nhi) break;
         { int span = nhi - ents[0].s; if (span > maxspan) maxspan = span; }
         double bc = INFINITY; int bs = -1;

@@ -22,7 +22,7 @@ class Cfg(C.Structure):
 class Out(C.Structure):
     _fields_ = [("nodes", C.c_longlong), ("edges", C.c_longlong), ("maxspan", C.c_longlong), ("maxlayer", C.c_longlong), ("rounds64", C.c_longlong), ("flat3", C.c_longlong), ("flat10", C.c_longlong), ("flat30", C.c_longlong), ("tspan", C.c_longlong), ("tspan_over", C.c_longlong),
                 ("best_t", C.c_int), ("cost", C.c_double), ("complete", C.c_int), ("per_layer", C.c_longlong * 64),
-                ("lay_kmin", C.c_double * 64), ("lay_band", C.c_double * 64), ("watch_c", C.c_double * 64), ("watch_sel", C.c_int * 64)]
+                ("lay_kmin", C.c_double * 64), ("lay_band", C.c_double * 64), ("watch_c", C.c_double * 64), ("watch_sel", C.c_int * 64), ("per_layer_span", C.c_longlong * 64), ("per_layer_off", C.c_longlong * 64)]
 
 def setup(wl="h40a21"):
     pkg.apply_overrides(pkg.REFERENCE_DEFAULT)

@@ -9,7 +9,7 @@
                                                                 DeterministicPolicyNetwork: tanh(.) * 5 + 0
 
 Here the network is 21 -> 400 -> ReLU -> 300 -> ReLU -> 1 with the tensors of the reference's ``pretrained_models/ddpg_*_extended/policy.pt``
-(exported as data by ``tests/golden/make_actor_weights.py``), float32 like the reference's, squash ``tanh * tanh_scale + tanh_mean``, in
+(exported as data by ``data/make_actor_weights.py`` next to this file, into ``data/``), float32 like the reference's, squash ``tanh * tanh_scale + tanh_mean``, in
 two interchangeable engines:
 
 * ``engine="hip"`` (default): ONE launch per evaluation, ``k_actor_eval`` (``stmpc_actor_eval_device``): state vector, both hidden layers on
@@ -19,7 +19,7 @@ two interchangeable engines:
 
 Parity: the 20 state-vector entries and the network's weights are the reference's own (pinned by ``golden_combined_real.npz``); the
 float32 cast and the TimeFeature input restate ``autonomous-learning-library`` 0.5.3 (requirements.txt:10), which is absent from the
-reference checkout -- parity unpinned for those two steps, and ``tests/test_actor.py`` measures how much the decisions depend on them.
+reference checkout -- parity unpinned for those two steps, and the suite's ``test_actor.py`` measures how much the decisions depend on them.
 """
 import os
 
@@ -27,7 +27,7 @@ import numpy as np
 
 from . import _capi
 
-ACTOR_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+ACTOR_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")      # package data: the reference's pretrained_models/*/policy.pt as tensors
 #: MODEL_NAME of the shipped evaluation configs -> exported tensor file (configs/combined_<traffic>_1.json:4)
 PRETRAINED = ("low1", "medium1", "default1", "moderate1", "fast1")
 
@@ -43,7 +43,7 @@ def weights_path(name):
         short = short[:-9]
     path = os.path.join(ACTOR_DIR, "actor_ddpg_%s.npz" % short)
     if not os.path.exists(path):
-        raise FileNotFoundError("no exported actor for %r (have: %s); tests/golden/make_actor_weights.py writes them" % (name, ", ".join(PRETRAINED)))
+        raise FileNotFoundError("no exported actor for %r (have: %s); data/make_actor_weights.py writes them" % (name, ", ".join(PRETRAINED)))
     return path
 
 
@@ -57,7 +57,7 @@ def load_weights(name):
 
 def state_vector_host(S, ego4, xs, vs, accs, evaluations=None):
     """Host twin of ``k_policy_features`` for ONE state (numpy, same operations): dqn.get_state_vector_from_base_state, the float32 cast and,
-    if ``evaluations`` is given, the TimeFeature input.  Used by the CPU tests; the product path is the kernel."""
+    if ``evaluations`` is given, the TimeFeature input.  Used by the CPU suite; the product path is the kernel."""
     fc = _capi.FeaturesCfg.from_settings(S, time_feature=evaluations is not None)
     tw = 4 if fc.use_acceleration else 3
     out = np.zeros((fc.cars_ahead + fc.cars_behind) * tw + 4 + (1 if fc.time_feature else 0), dtype=np.float32)
@@ -124,7 +124,7 @@ class DDPGActor:
         self.evals = torch.zeros(self.n, dtype=torch.int32, device=dev)
         self.feat = torch.empty(self.n, self.flen, dtype=torch.float32, device=dev)
         self.jerk = torch.empty(self.n, dtype=torch.float64, device=dev)
-        self.keep_features = False                # hip engine: also write the input vectors to ``self.feat`` (tests)
+        self.keep_features = False                # hip engine: also write the input vectors to ``self.feat`` (parity checks)
         self.handle = ctx.actor_create(w) if engine == "hip" else None
 
     def __del__(self):
@@ -168,7 +168,7 @@ class DDPGActor:
 
 
 def forward_host(w, feat, dtype=np.float32):
-    """The network on the host in numpy (CPU tests): feat [n, 21] -> jerk [n]."""
+    """The network on the host in numpy (CPU suite): feat [n, 21] -> jerk [n]."""
     x = np.asarray(feat, dtype=dtype)
     h = np.maximum(x @ w["w0"].T.astype(dtype) + w["b0"].astype(dtype), 0)
     h = np.maximum(h @ w["w1"].T.astype(dtype) + w["b1"].astype(dtype), 0)

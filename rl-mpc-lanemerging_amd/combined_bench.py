@@ -2,7 +2,7 @@
 ``configs/combined_medium_1.json``: EVALUATE_COMBINED_DDPG, dqn.py:117-200) for N states, everything on the device.
 
 The actor is the reference's own pretrained network of that config (``MODEL_NAME runs/ddpg_medium1_extended`` =
-``pretrained_models/ddpg_medium1_extended/policy.pt``, its tensors exported as data by tests/golden/make_actor_weights.py): 21 -> 400 ->
+``pretrained_models/ddpg_medium1_extended/policy.pt``, its tensors exported as data by data/make_actor_weights.py): 21 -> 400 ->
 300 -> 1, ReLU, 5 x tanh (ddpg.py:29-41,83-87), evaluated in float32 on PyTorch-ROCm and fed by ``k_policy_features`` (``actor.DDPGActor``).
 A tick = ROLLOUT_LENGTH policy evaluations + rollout steps, the feasibility probe solve of the rolled-out state, the controller solve
 (lattice search + QP re-sampling) of the start states whose decision hands control over, and the decision rules.
@@ -101,6 +101,6 @@ def run(args, rank, world, dev, dist):
            "decisions": {"policy_kept": int((reason == 0).sum()), "crash_predicted": int((reason == 1).sum()), "too_fast": int((reason == 2).sum()),
                          "probe_rejected": int((reason == 3).sum()), "st_better": int((reason == 4).sum())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["parity_note"] = ("decisions with this actor are pinned by tests/test_actor.py against golden_combined_real.npz (the reference's do_combined_control with the same "
-                              "network); the decision logic by tests/test_combined.py; this workload has no CPU baseline leg")
+        out["parity_note"] = ("decisions with this actor are pinned by the suite (test_actor.py) against golden_combined_real.npz (the reference's do_combined_control with the same "
+                              "network); the decision logic by test_combined.py; this workload has no CPU baseline leg")
     return out

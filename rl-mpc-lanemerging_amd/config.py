@@ -78,7 +78,7 @@ class Settings:
 
     @classmethod
     def snapshot(cls):
-        """Copy of the current solver flags (used by tests to restore state)."""
+        """Copy of the current solver flags (used by the suite to restore state)."""
         return dict(cls.export_settings())
 
     @classmethod

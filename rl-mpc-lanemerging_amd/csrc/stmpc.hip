@@ -867,6 +867,9 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
             hipLaunchKernelGGL((k_solve<L, false, FD, KT_, FM, SG, RS, 88>), grid, block, lds, lst, a);       \
         } while (0)
+#ifndef STMPC_FAN1
+#define STMPC_FAN1 8        /* candidate slots per barrier pair of the wide-lattice kernels outside the standard second window (128 VGPRs); 7 / 11 / 12 measured in round 5, 12 again in round 6 */
+#endif
 #ifndef STMPC_FAN88
 #define STMPC_FAN88 24      /* candidate slots per barrier pair in the standard second window (it has the registers: 256 VGPRs); 12 / 16 / 21 / 24 measured, EXPERIMENTS.md */
 #endif
@@ -878,7 +881,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         // checkpointing variants only where they are used: the first window saves, the second continues
 #define STMPC_LAUNCH_S(L, FD, KT_, FM, SG)                                                                    \
         do {                                                                                                  \
-            if constexpr (L && FM == 8 && KT_ == 0) {                                                        \
+            if constexpr (L && FM == STMPC_FAN1 && KT_ == 0) {                                                        \
                 if (resume && k == 0 && std_shape) STMPC_LAUNCH_R4(L, FD, KT_, FM, SG, 1);               \
                 else if (resume && k == 0) STMPC_LAUNCH_R(L, FD, KT_, FM, SG, 1);                             \
                 else if (resume && k == 1 && std_shape2) STMPC_LAUNCH_R88(L, FD, KT_, STMPC_FAN88, SG, 2);    \
@@ -888,7 +891,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         } while (0)
         // only the last tier carries the general lattice-coordinate form (see solve_episode)
 #define STMPC_LAUNCH(L, FD, KT_, FM) do { if (a.last_tier) STMPC_LAUNCH_S(L, FD, KT_, FM, true); else STMPC_LAUNCH_S(L, FD, KT_, FM, false); } while (0)
-#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 9); else STMPC_LAUNCH(L, FD, KT_, 8); } while (0)
+#define STMPC_LAUNCH_FM(L, FD, KT_) do { if (small_fan) STMPC_LAUNCH(L, FD, KT_, 9); else STMPC_LAUNCH(L, FD, KT_, STMPC_FAN1); } while (0)
         if (tierLds[k]) {
             if (stage_tab) { if (fastdiv) STMPC_LAUNCH_FM(true, true, 8); else STMPC_LAUNCH_FM(true, false, 8); }
             else { if (fastdiv) STMPC_LAUNCH_FM(true, true, 0); else STMPC_LAUNCH_FM(true, false, 0); }

@@ -1197,6 +1197,9 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
             // (chosen per round: the short last round of a wide layer is spread as well)
             int gsh = 0;
             if (relax) { while (gsh < a.gsh_max && ((nlist - r0) << (gsh + 1)) <= per) ++gsh; }
+#ifdef STMPC_EXP_GSH_MIN      /* experiment (round 6): every source on at least 2^STMPC_EXP_GSH_MIN lanes through range, filter and candidates */
+            if (relax && MODE == PASS_EXACT && gsh < STMPC_EXP_GSH_MIN) gsh = STMPC_EXP_GSH_MIN;
+#endif
             const int sub = tid & ((1 << gsh) - 1);
             rstep = per >> gsh;
             const int srcidx = r0 + (tid >> gsh);

@@ -11,8 +11,8 @@ pickle names -- ``all.policies.deterministic.DeterministicPolicyNetwork`` and ``
     model.4  Linear0 300 -> 1      (an nn.Linear initialised to zero)
     output = tanh(model(x)) * _tanh_scale + _tanh_mean     (action space Box(MINIMUM_NEGATIVE_JERK, MAXIMUM_POSITIVE_JERK), merge_gym.py:220-222)
 
-Writes tests/golden/actor_ddpg_<name>.npz with w0,b0,w1,b1,w2,b2 (float32, as stored), tanh_scale, tanh_mean.
-Re-run:  python tests/golden/make_actor_weights.py
+Writes actor_ddpg_<name>.npz next to this script (package data: ``actor.ACTOR_DIR``) with w0,b0,w1,b1,w2,b2 (float32, as stored), tanh_scale, tanh_mean.
+Re-run:  python rl-mpc-lanemerging_amd/data/make_actor_weights.py
 """
 import os
 import pickle

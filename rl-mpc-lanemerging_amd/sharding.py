@@ -1,7 +1,7 @@
 """Multi-GPU: merge episodes are independent, so a batch is block-partitioned over ranks
 (one process per GPU); the only exchange is one all-gather of the chosen action (next cell)
 and its cost, 16 B per episode, over RCCL/xGMI (``torch.distributed`` backend "nccl"), or
-gloo on CPU for tests.  No data-path collective exists anywhere else in the path.
+gloo on CPU for the suite.  No data-path collective exists anywhere else in the path.
 """
 import numpy as np
 

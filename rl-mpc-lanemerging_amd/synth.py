@@ -1,4 +1,4 @@
-"""Seeded synthetic merge states for tests and ``bench.py``.
+"""Seeded synthetic merge states for the suite and ``bench.py``.
 
 Not taken from the reference (it has no generator: states come from SUMO); the
 distributions follow the reference's scenario constants -- ramp/highway geometry

@@ -185,6 +185,21 @@ def test_product_does_not_import_oracle():
     assert "oracle" not in open(os.path.join(REPO, "include", "stmpc.h")).read()
 
 
+def test_pretrained_actors_are_package_data():
+    """The reference's pretrained actors (pretrained_models/*/policy.pt as tensors; configs/combined_medium_1.json:4 names one by MODEL_NAME) ship
+    inside the package, and no module of the package refers to the test tree."""
+    from rl_mpc_lanemerging_amd import actor
+    pkgdir = os.path.realpath(os.path.join(REPO, "rl-mpc-lanemerging_amd"))
+    for name in ("runs/ddpg_medium1_extended", "ddpg_low1", "default1", "moderate1", "fast1"):
+        path = os.path.realpath(actor.weights_path(name))
+        assert path.startswith(pkgdir + os.sep), path
+        w = actor.load_weights(name)
+        assert w["w0"].shape == (400, 21) and w["w1"].shape == (300, 400) and w["w2"].shape == (1, 300)
+    for f in os.listdir(pkgdir):
+        if f.endswith(".py"):
+            assert "tests" not in open(os.path.join(pkgdir, f)).read(), f
+
+
 def test_synth_generator_is_seeded_and_ordered():
     from rl_mpc_lanemerging_amd import synth
     a = synth.generate_states(64, seed=3)
