@@ -187,6 +187,7 @@ struct stmpc_ctx {
     int *h_overflow = nullptr, *d_overflow = nullptr;   // mapped pinned word: episodes that overflowed the first window in the batch before this one (stored by the
                                    // batch's last launch straight into host memory -- no copy, no stall --, read, possibly one batch late, when the next one
                                    // is set up): the narrow lattice starts its second window alongside the first only when there was something for it to do
+    double last_infl = 1.005;      // STMPC_LAST_INFL: the exact pass's candidate filter lets terminals up to this factor above the bound through (SolveArgs::last_infl); 1 = off
     double bound_infl = 1.00002;   // STMPC_BOUND_INFL: factor on a bounding pass's single-precision path cost (>= 1.00002, the rounding of that total)
     int qp_maxiters = STMPC_QP_MAXITERS;   // STMPC_QP_ITERS (experiment: the iteration cap of st.do_st_control's QP; the reference's is 10, st.py:17)
     int tube_w = 96;               // STMPC_TUBE=w: half-width (cells) of the guided bounding attempt, 0 = off (see SolveArgs::guide_tab)
@@ -310,6 +311,7 @@ int stmpc_create(stmpc_ctx **out, int device) {
     if (const char *w = getenv("STMPC_HEAVY_FIRST")) c->heavy_first = atoi(w) != 0;
     if (const char *w = getenv("STMPC_GSH")) { int v = atoi(w); if (v >= 0 && v <= 4) c->gsh_max = v; }
     if (const char *w = getenv("STMPC_RESUME")) c->resume = atoi(w) != 0;
+    if (const char *w = getenv("STMPC_LAST_INFL")) { double v = atof(w); if (v >= 1.0 && v <= 4.0) c->last_infl = v; }
     if (const char *w = getenv("STMPC_BOUND_INFL")) { double v = atof(w); if (v >= 1.00002 && v <= 2.0) c->bound_infl = v; }
     if (const char *w = getenv("STMPC_POOL")) { int v = atoi(w); if (v >= 1) c->pool_cap_override = v; }
     if (const char *w = getenv("STMPC_QP_ITERS")) { int v = atoi(w); if (v >= 0 && v <= 1000) c->qp_maxiters = v; }
@@ -795,7 +797,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
     }
     a.band_cap = c->band_cap;
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
-    a.bound_infl = c->bound_infl;
+    a.bound_infl = c->bound_infl; a.last_infl = c->last_infl;
     a.guide = g_cells; a.tube_w = c->tube_w; a.tube_dense = c->tube_dense; a.band_dense = c->band_dense;
     a.retry_move = resume ? c->retry_move : 0;
     a.prio_thr = c->prio_thr; a.prio_mode = c->prio_mode;
@@ -1093,7 +1095,7 @@ int stmpc_solve_grid(stmpc_ctx *c, const uint8_t *obstacles, const double *s_val
     memset(&a, 0, sizeof a);
     a.p = dp; a.N = 1; a.Kmax = 1; a.W = Wg; a.PW = Wg; a.last_tier = 1;
     for (int i = 0; i < 3; ++i) a.retry_mult[i] = c->retry_mult[i];
-    a.bound_infl = c->bound_infl;
+    a.bound_infl = c->bound_infl; a.last_infl = c->last_infl;
     a.obstacles = c->s_misc0.as<uint8_t>(); a.distances = c->s_misc1.as<double>(); a.s_values = c->s_misc2.as<double>();
     a.S_grid = S; a.v0_grid = v0; a.a0_grid = a0; a.gsh_max = c->gsh_max;
     a.bp = c->bp_tier[STMPC_MAX_TIERS - 1].as<u16>(); a.gscratch = c->gscratch.as<unsigned char>(); a.counters = c->counters.as<unsigned>();

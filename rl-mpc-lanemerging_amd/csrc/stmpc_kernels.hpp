@@ -742,6 +742,7 @@ struct SolveArgs {
     int prio_thr;          // first window: an overflowing search with more than this much left (layers x nodes) joins the front class of the next queue; 0 = off
     int retry_move;        // first window: after this many failed exact passes of an episode the next one runs in the second window (0 = never)
     double bound_infl;     // a bounding pass's single-precision total times this is the bound (its rounding alone needs 1.00002; see stmpc.hip)
+    double last_infl;      // exact pass: factor on the bound in the candidate filter of the step INTO the last layer (>= 1; see dp_pass, vmin_bits)
     double retry_mult[3];  // growth of a bound that turned out to be below the reference's terminal cost: first, second, third repeat (then unbounded)
     unsigned *cu_tab;      // null = off
     int retire_from;
@@ -801,6 +802,7 @@ struct PassOut {
     int nodes;         // expanded nodes
     int maxspan;       // widest live span (cells) the pass needed
     int pool;          // first window, return code 2: pool entry that holds the saved layer and the back-pointer rows
+    u64 vmin_bits;     // exact pass that ended without a terminal within its bound: cheapest node of the LAST layer (all of them above the bound), ~0 = none
 };
 
 // Workgroup-shared scratch of one episode (LDS in every variant).
@@ -949,6 +951,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
     int total_nodes = 0;
     int maxspan = 0;
     int last_t = -1;               // PASS_EXACT: deepest layer that had nodes to expand
+    int died_t = -1;               // layer whose scan found nothing to expand
     // Dense layers (narrow-lattice kernels, unbounded exact pass: the reference's own lattice).  98 % of the cells between the lowest and the highest
     // reached cell of a layer ARE reached there (measured on the benchmark batch: 420 nodes in a span of 429), so the list of cells to expand is the
     // span itself: no scan, no compaction, no list lookup in front of every source's cost and history -- a fifth of this pass's time.  A cell of the
@@ -968,6 +971,10 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         int my_best_n = 0x7fffffff;
         u64 my_min_tot = ~0ull;
         u64 thr = ubits;
+        // bound the candidate filter works with: the pass's bound, but last_infl times that for the step into the last layer, so that terminals just
+        // above the bound are still recorded: if the pass then ends without a terminal within its bound, the cheapest of them bounds the repeat
+        // (out.vmin_bits) -- each is the cost of a real path of exact nodes, hence >= what the reference's search holds for that cell, hence >= its terminal
+        const double filt_u = (MODE == PASS_EXACT && ubits < INF_BITS) ? __longlong_as_double((long long)ubits) * ((t == H - 2) ? a.last_infl : 1.0) : 0.0;
         int tube_c = 0, tube_lo = 0, tube_hi = 0x7fffffff;       // guided bounding pass: centre of this layer's tube, cell range of the next layer's
         if constexpr (MODE == PASS_BOUND) {
             if (tube_w > 0) {
@@ -1149,7 +1156,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                 bandt = bandt > band ? band : (bandt < 0.05 * band ? 0.05 * band : bandt);
             }
         }
-        if (nlist == 0) break;               // nothing to expand in layer t: the deepest layer reached is t-1
+        if (nlist == 0) { died_t = t; break; }      // nothing to expand in layer t: the deepest layer reached is t-1
         const double rad_b = (MODE == PASS_BOUND && nk.ok) ? (double)__builtin_amdgcn_sqrtf((float)(bandt * nk.invK)) : 0.0;   // half-width of the bounding pass's candidate interval (metres)
         const int smin = __builtin_amdgcn_readfirstlane(list_at(nlist - 1));      // lowest source of the layer (list[] is final since S1)
         if constexpr (MODE == PASS_EXACT) {
@@ -1264,7 +1271,7 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
                             edge_quad_source(nk, sv - p1, p1 - p2, m_, emin, &mag);
                             // slack inflated by 1e-9 relative and absolute against the rounding of the evaluated cost, and by 1e-12 of the
                             // magnitude emin is a difference of (its own rounding: a few 1e-16 of that)
-                            const double slack = __builtin_fma(__longlong_as_double((long long)ubits) - C, 1.0 + 1e-9, __builtin_fma(mag, 1e-12, 1e-9));
+                            const double slack = __builtin_fma(filt_u - C, 1.0 + 1e-9, __builtin_fma(mag, 1e-12, 1e-9));
                             const double room = slack - emin;
                             if (!(room >= 0.0)) { if (hi > lo) cut_l = true; lo = 0; hi = 0; }
                             else {
@@ -1601,6 +1608,23 @@ __device__ int dp_pass(const SolveArgs &a, const Ep &ep, WgShared &sh, u64 *cost
         }
     }
     STMPC_PH_FLUSH(MODE);
+    out.vmin_bits = ~0ull;
+    if constexpr (MODE == PASS_EXACT && !GRID) {
+        // A bounded pass that built the last layer and found every node of it above the bound: their cheapest (one sweep over the layer's
+        // cells, outside every hot loop) is the bound of the repeat (solve_episode) -- never below the reference's terminal, and equal to it
+        // whenever the reference's path was cut in its last step only, which is the usual way for a bound 0.00-0.2 % too low to fail.
+        if (died_t == H - 1 && ubits < INF_BITS && whi > wlo) {
+            u64 m = ~0ull;
+            for (int n = wlo + tid; n < whi; n += per) { const u64 c_ = M::ld64(&cost[n & WM]); m = c_ < m ? c_ : m; }
+            m = wave_min_u64(m);
+            if (lane == 0) sh.min_tot[wave] = m;
+            M::barrier();
+            u64 mt = ~0ull;
+            for (int w = 0; w < NW; ++w) { const u64 m_ = sh.min_tot[w]; mt = m_ < mt ? m_ : mt; }
+            if (mt < INF_BITS) out.vmin_bits = mt;
+            M::barrier();
+        }
+    }
     if constexpr (MODE == PASS_EXACT) {
         // the terminal of the search (st_cy.pyx:365-369): cheapest node of the deepest non-empty layer, smallest cell among equals
         if (last_t >= 0) {
@@ -2130,7 +2154,8 @@ __device__ int solve_episode(const SolveArgs &a, int e, int slot, WgShared &sh, 
         if (out.best_t == H - 1 || !out.pruned) break;
         // the bound was below the reference's terminal cost (its search is not globally optimal): relax it
         // (growth factors: SolveArgs::retry_mult)
-        if (attempt >= 3) ubits = INF_BITS;
+        if (out.vmin_bits != ~0ull && out.vmin_bits > ubits) ubits = out.vmin_bits;      // a complete path's exact cost, >= the reference's terminal: this repeat cannot fail (dp_pass)
+        else if (attempt >= 3) ubits = INF_BITS;
         else ubits = (u64)__double_as_longlong(__longlong_as_double((long long)ubits) * (attempt == 0 ? a.retry_mult[0] : (attempt == 1 ? a.retry_mult[1] : a.retry_mult[2])));
         if (tid == 0) atomicAdd(&a.counters[STMPC_CNT_RETRY], 1u);
         if constexpr (!GRID && RES == 1) {
