@@ -45,6 +45,8 @@ def parse_args():
                          "environments with configs/train_moderate_1.json's traffic under that controller (BASELINE configs[4] as a labelled "
                          "throughput demo: the reference has no counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object of the headline line (the reference's own lattice, st.do_st_control and "
+                    "the combined controller's tick, each a short timed run in the same process after the headline loop)")
     ap.add_argument("--pipelined", type=int, default=2, help="also report the throughput with this many batches in flight (one context, stream and "
                     "output buffers each; 0/1 = skip); the headline value is always one batch at a time")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock target per CPU solver (heap, layered) of the cpu_baseline sample")
@@ -122,6 +124,85 @@ def cpu_baseline(orc, op, ego, kc, ox, ov, seconds):
     return out, counts, one
 
 
+def secondary_workloads(args, dev, local_rank, np, torch, pkg, _capi, synth):
+    """The other BASELINE configs in the driver's one run: configs[0]'s parameters (configs/st_low.json:14-25 = the reference's own lattice, H=18,
+    S=3001, fan-out <= 6) as a batched solve with every episode against the oracle, `st.do_st_control` on the same states (lattice search + QP
+    re-sampling + commanded speed, st.py:757-783), and configs[2] (configs/combined_medium_1.json: one tick of dqn.RLAgent.do_combined_control,
+    dqn.py:117-200, with the reference's pretrained ddpg_medium1 actor).  Each: own context, args.warmup + args.steps steps, timed like the headline
+    (synchronise, wall clock).  Returns the `secondary` object; the headline's Settings are restored by the caller."""
+    from oracle import st_oracle as orc
+    out = {}
+    n, K, Kmax = 4096, 6, 8
+    steps, warm = max(args.steps, 5), max(args.warmup, 2)
+    pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+    S = pkg.Settings
+    params = _capi.Params.from_settings(S)
+    H = _capi.num_t(params)
+    ego, kc, ox, ov = synth.generate_states(n, k=K, kmax=Kmax, seed=1000)
+    ctx = _capi.Context(local_rank)
+    te, tk, tx, tv = (torch.as_tensor(a_, device=dev) for a_ in (ego, kc, ox, ov))
+    o_path = torch.empty((n, H), dtype=torch.int32, device=dev); o_bt = torch.empty(n, dtype=torch.int32, device=dev)
+    o_cost = torch.empty(n, dtype=torch.float64, device=dev); o_pd = torch.empty((n, H), dtype=torch.float64, device=dev)
+    o_crash = torch.empty(n, dtype=torch.int32, device=dev)
+    o_speed = torch.empty(n, dtype=torch.float64, device=dev)
+    o_fine = torch.zeros((n, _capi.QP_NMAX), dtype=torch.float64, device=dev); o_fl = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - c0
+
+    def solve():
+        ctx.solve_batch_device(params, n, Kmax, te.data_ptr(), tk.data_ptr(), tx.data_ptr(), tv.data_ptr(), o_path.data_ptr(), o_bt.data_ptr(),
+                               o_cost.data_ptr(), o_pd.data_ptr(), o_crash.data_ptr(), torch.cuda.current_stream().cuda_stream, 0)
+    el = timed(solve)
+    c0 = time.perf_counter()
+    ref = orc.solve_batch(orc.OrcParams.from_dict(params.as_dict()), ego, kc, ox, ov, solver="layered", nthreads=cpu_info()[3])
+    t_orc = time.perf_counter() - c0
+    got = {"path_idx": o_path.cpu().numpy(), "best_t": o_bt.cpu().numpy(), "cost": o_cost.cpu().numpy(), "crash": o_crash.cpu().numpy()}
+    out["reference_lattice"] = {"metric": "MPC solves/sec (reference default H=%d,S=%d,K=%d; configs/st_low.json parameters)" % (H, _capi.num_s(params, 0.0), K),
+                                "value": n * steps / el, "unit": "solves/s", "ms_per_step": el / steps * 1e3, "episodes": n, "steps": steps,
+                                "parity_vs_oracle": {"episodes": n, **{k_: bool(np.array_equal(got[k_], ref[k_])) for k_ in got}},
+                                "oracle_solves_per_s": n / t_orc}
+
+    def control():
+        ctx.st_control_batch_device(params, S.TICK_LENGTH, n, Kmax, te.data_ptr(), tk.data_ptr(), tx.data_ptr(), tv.data_ptr(), o_path.data_ptr(),
+                                    o_bt.data_ptr(), o_cost.data_ptr(), o_speed.data_ptr(), o_fine.data_ptr(), o_fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    el = timed(control)
+    from oracle import ff_oracle as ff
+    from rl_mpc_lanemerging_amd import st as st_mod
+    fs = ff.settings(S.MAX_SPEED, S.MAX_POSITIVE_ACCELERATION, S.MAX_NEGATIVE_ACCELERATION, S.MAXIMUM_POSITIVE_JERK, S.MINIMUM_NEGATIVE_JERK, S.CAR_LENGTH)
+    mq = 256
+    want = np.zeros(mq)
+    for i in range(mq):
+        bt_i = int(ref["best_t"][i])
+        s_seq = st_mod.s_values_for(ego[i, 4], params)[ref["path_idx"][i, :bt_i + 1]]
+        x = ff.finer_fit(s_seq, S.TICK_LENGTH, S.T_DISCRETIZATION, ego[i, 2], ego[i, 3], fs)[0]
+        want[i] = ego[i, 2] if len(x) <= 1 else (x[1] - x[0]) / S.TICK_LENGTH
+    out["st_control"] = {"metric": "st.do_st_control commanded speeds/sec (lattice search + QP re-sampling to the %.1f s tick)" % S.TICK_LENGTH,
+                         "value": n * steps / el, "unit": "speeds/s", "ms_per_step": el / steps * 1e3, "episodes": n, "steps": steps,
+                         "parity": {"episodes": mq, "path_idx": bool(np.array_equal(o_path.cpu().numpy(), ref["path_idx"])),
+                                    "speed_vs_own_qp_oracle": bool(np.array_equal(o_speed[:mq].cpu().numpy(), want)),
+                                    "note": "QP solve: parity unpinned (cvxopt absent); the oracle is this repo's restatement (oracle/ff_oracle.c)"}}
+    del ctx
+    from rl_mpc_lanemerging_amd import combined_bench
+    import copy
+    a2 = copy.copy(args)
+    a2.episodes, a2.steps, a2.warmup, a2.no_cpu_baseline = n, steps, warm, True
+    cb = combined_bench.run(a2, 0, 1, dev, None)
+    out["combined_tick"] = {"metric": cb["metric"], "value": cb["value"], "unit": cb["unit"], "ms_per_step": cb["ms_per_step"], "episodes": n, "steps": steps,
+                            "actor": cb["config"]["actor"], "decisions": cb["decisions"],
+                            "controller_solves_per_decision": cb["config"]["controller_solves_per_decision"],
+                            "actor_on_pytorch_rocm_ticks_per_s": cb["actor_on_pytorch_rocm"]["value"],
+                            "decisions_that_differ_between_the_two_actor_engines": cb["actor_on_pytorch_rocm"]["decisions_that_differ_from_the_fused_kernel"]}
+    return out
+
+
 def run(args):
     import numpy as np
     import torch
@@ -172,6 +253,9 @@ def run(args):
     # a fast-but-wrong build must not look like a result: any parity flag that is false fails the run (the line above says which)
     par = out.get("parity_vs_oracle") or {}
     bad = [k for k, v in par.items() if v is False]
+    sec = out.get("secondary") or {}
+    bad += ["secondary.reference_lattice." + k for k, v in (sec.get("reference_lattice", {}).get("parity_vs_oracle") or {}).items() if v is False]
+    bad += ["secondary.st_control." + k for k, v in (sec.get("st_control", {}).get("parity") or {}).items() if v is False]
     if out.get("pipelined") and out["pipelined"].get("outputs_identical_across_buffers") is False:
         bad.append("pipelined.outputs_identical_across_buffers")
     if bad:
@@ -231,9 +315,11 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         step()
     barrier()
     ctx.profile_begin()
+    cpu0 = time.thread_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    cpu1 = time.thread_time()      # CPU time this rank's thread spent ISSUING the steps (launches, the collective's enqueue), not waiting for them
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
@@ -362,6 +448,9 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                       "collective": ("all_gather(action,cost) 16 B/episode over RCCL, %d ranks" % world) if use_dist else "none",
                       "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-spawn" if world > 1 else "single")},
            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+           # what a rank's host side costs: with N ranks on one node the ranks share the container's CPU quota, and a step is ~10 launches + 1 collective
+           "host": {"host_us_per_step": (cpu1 - cpu0) / args.steps * 1e6, "cpus_in_affinity_mask": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                    "container_cpu_quota": cpu_info()[4], "note": "rank 0's figures; thread CPU time of the timed step loop / steps"},
            "rccl_ranks": (dist.get_world_size() if use_dist else 0),
            "library": {"backend": _capi.backend_info(), "csrc_hash": lib_hash, "measured_counters": measured_rel,
                        "measured_counters_csrc_hash": measured.get("csrc_hash"), "measured_counters_stale": measured_stale},
@@ -382,6 +471,15 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
         out["stages"] = {"lattice_search_ms": prof["solve_ms"] / max(prof["launches"], 1),
                          "qp_resampling_ms": ms_per_step - prof["solve_ms"] / max(prof["launches"], 1),
                          "note": "lattice search from HIP events inside the library; QP = step time minus that"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_secondary and args.workload == "h40a21" and args.episodes in (0, 4096):
+        # the other configs, witnessed by the same run (after the timed headline loop; nothing of the headline depends on it)
+        c0 = time.perf_counter()
+        try:
+            out["secondary"] = secondary_workloads(args, dev, local_rank, np, torch, pkg, _capi, synth)
+            out["secondary"]["wall_s"] = time.perf_counter() - c0
+        finally:
+            pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
+            pkg.apply_overrides(pkg.SYNTHETIC_H40A21)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import st_oracle as orc
         op = orc.OrcParams.from_dict(params.as_dict())
@@ -470,6 +568,16 @@ def _spawned(local_rank, args, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one disjoint set of CPUs per rank (the ranks' host threads -- launch loop, RCCL proxy -- then do not migrate onto each other); skipped when the
+    # process may not run on at least two CPUs per rank
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            per = len(cpus) // args.gpus
+            if per >= 2:
+                os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per])
+        except OSError:
+            pass
     run(args)
 
 

@@ -302,6 +302,7 @@ def test_bench_forced_rccl_single_rank():
     assert line["n_gpus"] == 1 and "all_gather" in line["config"]["collective"] and line["value"] > 0
     assert line["rccl_ranks"] == 1                     # the rank count RCCL itself reports
     assert line["config4_shard"]["episodes_per_gpu"] == 8192 and line["config4_shard"]["value"] > 0      # BASELINE configs[3]'s per-rank shard, timed in every multi-rank run
+    assert line["host"]["host_us_per_step"] > 0 and line["host"]["cpus_in_affinity_mask"] >= 1           # what a rank's host side costs (the 1 -> 8 GPU curve's other risk)
 
 
 def test_edge_cases(gpu_ctx, restore_settings):
