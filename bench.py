@@ -28,7 +28,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak
 # counters bench.py cannot regenerate itself (rocprofv3 --pmc passes, scripts/profile_gpu.sh + scripts/profile_summarize.py): the newest
 # round's file that exists.  Each workload entry carries the source hash of the library it was taken from ("csrc_hash"); the bench line says
 # "stale": true wherever it quotes such a counter and the running library was built from other sources.
-MEASURED_CANDIDATES = [os.path.join(REPO, "profiles", r, "measured.json") for r in ("r5", "r4", "r3")]
+MEASURED_CANDIDATES = [os.path.join(REPO, "profiles", r, "measured.json") for r in ("r6", "r5", "r4", "r3")]
 MEASURED = next((m for m in MEASURED_CANDIDATES if os.path.exists(m)), MEASURED_CANDIDATES[0])
 
 
@@ -432,6 +432,10 @@ def run_solver(args, rank, world, local_rank, dev, dist, np, torch, pkg, _capi, 
                 "traffic_source": measured.get("hbm_source"), "traffic_stale": measured_stale if measured.get("hbm_bytes_per_step") else None,
                 "kernel": "stmpc::k_solve<true,false,...> (LDS lattice DP; one launch per LDS window tier, summed per step)",
                 "kernel_ms": dp_ms, "bytes_per_solve": bytes_per_solve, "bytes_per_launch": bytes_per_solve * n,
+                # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/rN/<round>_summary.txt,
+                # written into measured.json by scripts/profile_summarize.py): must agree with kernel_ms; stale = taken from another build of the library
+                "rocprof_kernel_avg_ms": measured.get("dominant_kernel_avg_ms"), "rocprof_kernel": measured.get("dominant_kernel"),
+                "rocprof_stale": measured_stale if measured.get("dominant_kernel_avg_ms") else None,
                 "note": "algorithmic HBM bytes are %d B/solve (SURVEY 8d): the path is fp64-VALU/LDS-latency bound, not HBM bound; "
                         "see fp64_valu and issue for the bounds that apply" % bytes_per_solve}
 

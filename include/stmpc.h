@@ -72,7 +72,7 @@
 extern "C" {
 #endif
 
-#define STMPC_ABI_VERSION 5   /* bumped whenever an exported signature or struct layout changes; see stmpc_abi_version() */
+#define STMPC_ABI_VERSION 6   /* bumped whenever an exported signature, a struct layout or the accepted values of a field change (6: stmpc_sim_cfg.yield_overlap must be 2); see stmpc_abi_version() */
 
 #define STMPC_OK        0
 #define STMPC_EINVAL   -1   /* bad argument (NULL, size, Kmax/H/S out of range) */
@@ -424,14 +424,11 @@ typedef struct stmpc_sim_cfg {
      * defaults: emergencyDecel 9, width 1.8); speed_dev = deviation of the per-vehicle speed factor (0 in the simple distribution) */
     double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
     int32_t vary_traffic_start_times, randomize_start_speed, max_ticks;
-    int32_t yield_overlap;           /* what a highway vehicle does about an ego that is on the junction but whose rear (plus minGap) is not yet ahead of the vehicle's
-                                        front -- the ego "laps in": 0 = nothing until the lanes are less than a vehicle width apart; 1 = it follows the ego at once
-                                        (Krauss with a negative gap: brakes for a slow ego, not for a fast one); 2 = SUMO's link-leader rule as its effect shows in the
+    int32_t yield_overlap;           /* must be 2 (anything else: STMPC_EINVAL).  What a highway vehicle does about an ego that is on the junction but whose rear (plus
+                                        minGap) is not yet ahead of the vehicle's front -- the ego "laps in": SUMO's link-leader rule as its effect shows in the
                                         reference's "disruption" columns: a vehicle whose front is behind the ego's front is asked to STOP while the ego laps in
-                                        (emergency braking, whatever the ego's speed); 3 = as 2 for every vehicle that overlaps the ego at all; 4 = as 2, and a vehicle that
-                                        overlaps the ego with its front still ahead stops too if the ego is the faster of the two and the vehicle has not reached the
-                                        point where the lanes begin to overlap (x = -37.8; SUMO breaks the tie of two vehicles on a junction by speed).  The
-                                        package's default is 2 (DESIGN.md section 9 compares them) */
+                                        (emergency braking, whatever the ego's speed).  Rounds 3-5 compared four other rules under the values 0, 1, 3, 4 (DESIGN.md
+                                        section 9); round 6 froze the world at this one and removed them */
     uint64_t seed;
     const double *ego_route_xy;      /* HOST [ego_route_n][2]: polyline of the ego's lane centre line from the ramp's start to the junction exit, x strictly
                                         increasing (beyond its last point the ego keeps that point's y); read by stmpc_sim_init_device, which keeps a device

@@ -58,9 +58,11 @@ class CombinedCfg(C.Structure):
                 ("test_st_strictly_better", C.c_int32), ("remember_last_choice", C.c_int32), ("sparse_control", C.c_int32)]
 
     @classmethod
-    def from_settings(cls, S, sparse_control=True):
-        """``sparse_control`` (not a reference flag): solve st.do_st_control only for the states whose decision calls it, as the reference does
-        (one host round trip per decide call); False keeps the call fully asynchronous and solves every state."""
+    def from_settings(cls, S, sparse_control=False):
+        """``sparse_control`` (not a reference flag): False (the C-level default: a zeroed field) keeps ``stmpc_combined_decide_device`` fully asynchronous
+        -- nothing leaves the GPU, the call can be captured in a hipGraph -- and solves st.do_st_control for every state; True solves it only for
+        the states whose decision calls it, as the reference does, at the price of one host round trip per decide call (the count of those
+        states).  ``EpisodeRunner`` and the benchmarks ask for it explicitly."""
         return cls(sparse_control=int(bool(sparse_control)), tick_length=S.TICK_LENGTH, stop_x=S.STOP_X, rollout_length=int(S.ROLLOUT_LENGTH), st_test_rollouts=int(S.ST_TEST_ROLLOUTS),
                    check_rollout_crash=int(bool(S.CHECK_ROLLOUT_CRASH)), limit_dqn_speed=int(bool(getattr(S, "LIMIT_DQN_SPEED", False))),
                    test_rollout_state=int(bool(S.TEST_ROLLOUT_STATE)), test_st_strictly_better=int(bool(getattr(S, "TEST_ST_STRICTLY_BETTER", False))),
@@ -126,7 +128,7 @@ EXPORTS = (
     "stmpc_actor_create", "stmpc_actor_destroy", "stmpc_actor_eval_device",
 )
 SIM_NACC = 12        # STMPC_SIM_NACC
-ABI_VERSION = 5     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
+ABI_VERSION = 6     # STMPC_ABI_VERSION of include/stmpc.h this binding was written against
 
 QP_NMAX = 64        # STMPC_QP_NMAX
 QP_MAXITERS = 10    # STMPC_QP_MAXITERS (solvers.options['maxiters'], st.py:17)

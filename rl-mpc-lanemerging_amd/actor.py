@@ -141,8 +141,15 @@ class DDPGActor:
         else:
             self.evals.masked_fill_(mask, 0)
 
+    def _check_rows(self, cur_ego4, k, cur_ox, cur_ov, cur_oa):
+        # the kernels are launched for self.n states and write self.jerk / self.feat / self.evals of that length
+        for name, t_ in (("cur_ego4", cur_ego4), ("k", k), ("cur_ox", cur_ox), ("cur_ov", cur_ov), ("cur_oa", cur_oa)):
+            if t_ is not None and t_.shape[0] != self.n:
+                raise ValueError("%s has %d rows, this actor was built for %d states" % (name, t_.shape[0], self.n))
+
     def features(self, step, cur_ego4, k, cur_ox, cur_ov, cur_oa, stream=None):
         torch = self.torch
+        self._check_rows(cur_ego4, k, cur_ox, cur_ov, cur_oa)
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         self.ctx.policy_features_device(self.fcfg, self.n, cur_ox.shape[1], step, cur_ego4.data_ptr(), k.data_ptr(), cur_ox.data_ptr(), cur_ov.data_ptr(),
                                         cur_oa.data_ptr() if cur_oa is not None else 0, self.evals.data_ptr(), self.feat.data_ptr(), self.flen, stream)
@@ -157,6 +164,7 @@ class DDPGActor:
 
     def __call__(self, step, cur_ego4, k, cur_ox, cur_ov, cur_oa):
         if self.engine == "hip":
+            self._check_rows(cur_ego4, k, cur_ox, cur_ov, cur_oa)
             stream = self.torch.cuda.current_stream().cuda_stream
             self.ctx.actor_eval_device(self.handle, self.fcfg, self.n, cur_ox.shape[1], step, cur_ego4.data_ptr(), k.data_ptr(), cur_ox.data_ptr(),
                                        cur_ov.data_ptr(), cur_oa.data_ptr() if cur_oa is not None else 0, self.evals.data_ptr(),

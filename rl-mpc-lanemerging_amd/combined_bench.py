@@ -43,7 +43,7 @@ def run(args, rank, world, dev, dist):
     pkg.apply_overrides(COMBINED_MEDIUM_1)
     S = pkg.Settings
     params = _capi.Params.from_settings(S)
-    cfg = _capi.CombinedCfg.from_settings(S)
+    cfg = _capi.CombinedCfg.from_settings(S, sparse_control=True)      # as the reference: the controller solve only where the decision calls it
     n = args.episodes if args.episodes > 0 else 4096
     K, Kmax = 6, 8
     ego, kc, ox, ov, evals0 = bench_states(n, 3000 + rank, S)

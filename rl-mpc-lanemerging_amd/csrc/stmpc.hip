@@ -662,7 +662,10 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
         tierLdsBytes[nt] = ((stmpc_chunk_ints(Wg) * sizeof(int) + 15) & ~(size_t)15) + 16;
         // (a batch that sent more than a handful of episodes there -- e.g. identical reset states whose second lattice point is not start + step --
         // gets the full grid from the next step on)
-        tierGrid[nt] = (cleanup_only && c->last_hbm_tier_count <= 16) ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
+        // (the count comes from a mapped host word the batch's last launch stores itself, [1] of h_overflow: a caller that never reads statistics --
+        // EpisodeRunner, decide_batch_device -- gets the full grid as well)
+        const int64_t sent_last = c->h_overflow && c->last_has_hbm ? (int64_t)c->h_overflow[1] : 0;
+        tierGrid[nt] = (cleanup_only && c->last_hbm_tier_count <= 16 && sent_last <= 16) ? 16 : c->num_cu * (c->max_waves_per_cu / tierNW[nt] > 0 ? c->max_waves_per_cu / tierNW[nt] : 1); ++nt;
     }
     const int prune_on = c->prune < 0 ? (small_fan ? 0 : 1) : c->prune;
     // checkpoint / resume across the first two LDS windows (SolveArgs::ckpt, ::pool_bp): a search that cannot build a layer in the first window
@@ -726,7 +729,7 @@ int stmpc_solve_batch_device_ac(stmpc_ctx *c, const stmpc_params *p, int N, int 
     // 0.14 of a 1.0 ms step; alongside it, on a small grid, they are done when it ends -- but a side launch that finds nothing to do costs 40 us of
     // stream hand-overs, so it is started only when the previous batch on this context overflowed)
     if (!c->h_overflow) {
-        HIPCHK(hipHostMalloc((void **)&c->h_overflow, sizeof(int), hipHostMallocMapped)); *c->h_overflow = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_overflow, 2 * sizeof(int), hipHostMallocMapped)); c->h_overflow[0] = 0; c->h_overflow[1] = 0;
         HIPCHK(hipHostGetDevicePointer((void **)&c->d_overflow, c->h_overflow, 0));
     }
     const bool overlap_auto = prune_on != 0 || (small_fan && *c->h_overflow > 0);
@@ -1590,7 +1593,18 @@ int stmpc_actor_create(stmpc_ctx *c, int n_in, int h1, int h2, const float *w0, 
         (rc = upload(a->b1, vb1)) || (rc = upload(a->w2, vw2))) { stmpc_actor_destroy(a); return rc; }
     a->dev.p0 = a->p0.as<float>(); a->dev.b0 = a->b0.as<float>(); a->dev.p1 = a->p1.as<float>(); a->dev.b1 = a->b1.as<float>(); a->dev.w2 = a->w2.as<float>();
     a->dev.b2 = b2[0]; a->dev.scale = (float)tanh_scale; a->dev.mean = (float)tanh_mean; a->dev.n_in = n_in; a->dev.h1p = h1p; a->dev.h2p = h2p;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_actor_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the attribute belongs to the kernel, not to this actor: only ever raised, so that a narrower actor created later does not take the
+    // dynamic LDS away from a wider one that is still in use)
+    static size_t actor_lds_max[16] = {0};
+    size_t &lds_max = actor_lds_max[(unsigned)c->device & 15u];
+    if (lds > 48 * 1024 && lds > lds_max) {
+        if (hipFuncSetAttribute((const void *)k_actor_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            stmpc_actor_destroy(a);
+            return fail(STMPC_EHIP, "hipFuncSetAttribute(k_actor_eval, dynamic LDS) failed");
+        }
+        lds_max = lds;
+    }
     *out = a;
     return STMPC_OK;
 }
@@ -1813,7 +1827,8 @@ int make_simcfg(const stmpc_sim_cfg *g, sim::Cfg *c) {
         return fail(STMPC_EINVAL, "vehicle type parameters (accel, decel, tau, length, emergency decel, minGap, speed_dev) out of range");
     c->veh_accel = g->veh_accel; c->veh_decel = g->veh_decel; c->veh_min_gap = g->veh_min_gap; c->veh_tau = g->veh_tau; c->veh_emergency_decel = g->veh_emergency_decel;
     c->veh_length = g->veh_length; c->veh_width = g->veh_width; c->speed_dev = g->speed_dev;
-    c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->yield_overlap = g->yield_overlap; c->seed = g->seed;
+    c->vary_interval = g->vary_traffic_start_times; c->randomize_start_speed = g->randomize_start_speed; c->max_ticks = g->max_ticks; c->seed = g->seed;
+    if (g->yield_overlap != 2) return fail(STMPC_EINVAL, "stmpc_sim_cfg.yield_overlap must be 2 (the one junction rule since ABI v6)");
     c->route = nullptr; c->route_n = 0;          // (the device copy of the route belongs to the context: sim_route_of)
     c->disruption_min_s = g->disruption_min_s;
     return STMPC_OK;

@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(64) k_cc_scatter(int M, const int *__restrict_
 // acceleration limits and nothing else) moving along the centre line of its lanes (Cfg::route: ramp_0 and the junction's internal lane of
 // merge.net.xml -- the positions TraCI reports and the reference's planner and actors see).  The Krauss follow speed is SUMO's Euler form
 // (MSCFModel::maximumSafeStopSpeedEuler / maximumSafeFollowSpeed), a highway vehicle regards as its leader the vehicle ahead and, once the
-// ego is on the junction's internal lane or beyond, the ego if that is ahead of it; what it does while the ego laps in is Cfg::yield_overlap
-// (four rules, compared with the reference's "disruption" columns in DESIGN.md section 9); bodies collide
+// ego is on the junction's internal lane or beyond, the ego if that is ahead of it; while the ego laps in, a vehicle whose front is behind the
+// ego's front is asked to stop (the one junction rule since round 6; rounds 3-5 compared five); bodies collide
 // when they overlap along the lane while the converging lanes are less than a vehicle width apart.  This is a restatement of
 // SUMO's documented models, not SUMO: episode statistics compare with the reference's reports as DISTRIBUTIONS -- and are labelled so.
 // One thread per environment; vehicles live in [N][KS] arrays, front to back.
@@ -273,7 +273,7 @@ struct Cfg {
     double tick, other_speed, base_interval, spawn_x, despawn_x, ego_start_x, ego_start_y, arrive_x, sensor_radius;
     double start_speed, start_speed_std, min_start_speed, max_start_speed;
     double veh_accel, veh_decel, veh_min_gap, veh_tau, veh_emergency_decel, veh_length, veh_width, speed_dev;
-    int vary_interval, randomize_start_speed, max_ticks, yield_overlap;
+    int vary_interval, randomize_start_speed, max_ticks;
     unsigned long long seed;
     const double *route;           // device [2][route_n]: x then y of the ego's lane centre line (nullptr: straight lines)
     int route_n;
@@ -426,7 +426,6 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
     const double ego_pos1 = ego_lane_pos(px, py);
     // lateral distance of the converging lanes at the ego's position: bodies can touch only where it is below a vehicle width
     const double lat = px < 1.5 ? 3.31 * (1.5 - px) / 52.08 : 0.0;
-    const double lat0 = cx < 1.5 ? 3.31 * (1.5 - cx) / 52.08 : 0.0;              // (the same at the start of the step)
     for (int i = 0; i < n; ++i) {
         const double ox_ = s.vx[(size_t)e * KS + i], ov_ = s.vv[(size_t)e * KS + i];
         double vnext = ov_ + c.veh_accel * dt;                                    // maxNextSpeed
@@ -436,24 +435,17 @@ __global__ void __launch_bounds__(64) k_sim_step(DevP p, Cfg c, int N, State s, 
             const double vs = krauss_follow(c, lead_x - c.veh_length - ox_ - c.veh_min_gap, lead_v);
             vnext = vs < vnext ? vs : vnext;
         }
-        // the ego is a leader too (it may be closer than the vehicle ahead) once it is on the junction: Cfg::yield_overlap says from when on
-        if (ego_on_lane && c.yield_overlap >= 2) {
+        // the ego is a leader too (it may be closer than the vehicle ahead) once it is on the junction
+        if (ego_on_lane) {
             // SUMO's link leader on merging internal lanes, restated from its observable effect (the reference's "disruption" columns: the vehicle
             // behind an ego that cuts in brakes at its EMERGENCY deceleration for ~3 ticks however fast the ego is; MSVehicle::getSafeFollowSpeed's
             // branch for a negative gap asks for a stop, not for a follow speed): with room behind the ego's rear (net of minGap) the vehicle
-            // follows it like any leader; while the ego laps in, a vehicle whose front is behind the ego's front (rule 2) -- or that overlaps
-            // the ego at all (rule 3), or overlaps it, is the slower of the two and has not reached the lanes' overlap at x = -37.8 (rule 4) --
-            // is asked to stop, i.e. brakes as hard as it can until the ego's rear is clear
+            // follows it like any leader; while the ego laps in, a vehicle whose front is behind the ego's front is asked to stop, i.e. brakes
+            // as hard as it can until the ego's rear is clear.  (The one rule kept: "rule 2" of round 5's comparison, frozen in round 6.)
             const double g_net = ego_pos0 - c.veh_length - ox_ - c.veh_min_gap;
             double vs = __builtin_inf();
             if (g_net >= 0.0) vs = krauss_follow(c, g_net, v_prev);
-            else if (ego_pos0 > ox_ || (c.yield_overlap == 3 && ego_pos0 > ox_ - c.veh_length) ||
-                     (c.yield_overlap == 4 && ego_pos0 > ox_ - c.veh_length && v_prev > ov_ && ox_ < -37.8)) vs = 0.0;
-            vnext = vs < vnext ? vs : vnext;
-        } else if (ego_on_lane && (ego_pos0 - c.veh_length >= ox_ || (ego_pos0 > ox_ && (c.yield_overlap || lat0 < c.veh_width)))) {
-            // rules 0 / 1 (rounds 3-4): an ordinary Krauss follow once the ego's rear is ahead of this vehicle's front -- or, if the two overlap
-            // along the lane, at once (rule 1) / once the converging lanes are less than a vehicle width apart there (rule 0)
-            const double vs = krauss_follow(c, ego_pos0 - c.veh_length - ox_ - c.veh_min_gap, v_prev);
+            else if (ego_pos0 > ox_) vs = 0.0;
             vnext = vs < vnext ? vs : vnext;
         }
         const double vmin = ov_ - c.veh_emergency_decel * dt;                     // (a vehicle never brakes harder than its emergency deceleration)

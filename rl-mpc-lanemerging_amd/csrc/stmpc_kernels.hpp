@@ -755,7 +755,7 @@ struct SolveArgs {
     double *cost;          // [N]
     double *path_dist;     // [N][H] or null
     int *crash;            // [N] or null
-    int *host_overflow;    // null or a word in MAPPED HOST memory: the batch's last launch stores the number of episodes that overflowed the first window there
+    int *host_overflow;    // null or TWO words in MAPPED HOST memory: the batch's last launch stores the number of episodes that overflowed the first window / that were queued for the last tier there
     double *action_cost;   // [N][2] or null: (cell of the first step as a double, -1 if the path has none; cost) -- the fused row the multi-GPU gather moves
     double *s_sequence;    // grid mode: [H]
 };
@@ -2338,8 +2338,11 @@ __global__ void __launch_bounds__(512, ((FANMAX <= 12 && NWX != 88) ? STMPC_MIN_
                 return e_;
             }
         };
-        if (a.last_tier && !a.concurrent && a.host_overflow && blockIdx.x == 0 && tid == 0)      // (every earlier launch of the batch has finished: the count is final)
+        if (a.last_tier && !a.concurrent && a.host_overflow && blockIdx.x == 0 && tid == 0) {    // (every earlier launch of the batch has finished: the counts are final)
             __hip_atomic_store(a.host_overflow, (int)__hip_atomic_load(&a.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // [1]: episodes queued for THIS (the last) tier -- the host sizes the next batch's clean-up launch by it
+            __hip_atomic_store(a.host_overflow + 1, a.tier > 0 ? (int)__hip_atomic_load(&a.counters[4 * a.tier], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const unsigned long long t_begin = a.concurrent ? wall_clock64() : 0ull;
         if (a.tier == 0 && a.feeds_concurrent && tid == 0) atomicAdd(&a.counters[STMPC_CNT_RESIDENT], 1u);
         int my_rank = 0;

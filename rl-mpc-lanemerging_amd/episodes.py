@@ -33,12 +33,10 @@ def ego_start_position(route="lane"):
     return x0 + EGO_START_ARC * ux, y0 + EGO_START_ARC * uy
 
 
-def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None, route="default"):
-    """``route``: "lane" = the ego follows the centre line of its lanes in the reference's network (``scenario.py``; TraCI reports those
-    positions), None = the straight lines the planner assumes (prediction.py:46-59); "default" = ``STMPC_SIM_ROUTE`` (lane / straight), lane if unset."""
+def sim_cfg(seed=0, max_episode_length=100.0, route="lane"):
+    """``route``: "lane" (default) = the ego follows the centre line of its lanes in the reference's network (``scenario.py``; TraCI reports those
+    positions), None = the straight lines the planner assumes (prediction.py:46-59; the world of rounds 3-4, kept for the mechanics test)."""
     S = Settings
-    if route == "default":
-        route = None if os.environ.get("STMPC_SIM_ROUTE", "lane") == "straight" else "lane"
     ex, ey = ego_start_position(route)
     g = lambda name, default: getattr(S, name, default)
     return _capi.SimCfg(tick_length=S.TICK_LENGTH, other_car_speed=g("OTHER_CAR_SPEED", 7.0), base_traffic_interval=g("BASE_TRAFFIC_INTERVAL", 1.2),
@@ -49,7 +47,7 @@ def sim_cfg(seed=0, max_episode_length=100.0, yield_overlap=None, route="default
                         veh_accel=4.5, veh_decel=6.0, veh_min_gap=1.0, veh_tau=0.5, veh_emergency_decel=9.0, veh_length=g("CAR_LENGTH", 5.0), veh_width=1.8, speed_dev=0.0,
                         vary_traffic_start_times=int(bool(g("VARY_TRAFFIC_START_TIMES", True))),
                         randomize_start_speed=int(bool(g("RANDOMIZE_START_SPEED", True))), max_ticks=int(max_episode_length / S.TICK_LENGTH),
-                        yield_overlap=int(os.environ.get("STMPC_SIM_YIELD_OVERLAP", "2")) if yield_overlap is None else int(yield_overlap),
+                        yield_overlap=2,          # (the one junction rule, include/stmpc.h)
                         seed=int(seed), disruption_min_s=float(g("MERGE_POINT_X", -50.0))).set_route(np.stack(scenario.lane_polyline()[:2], axis=1) if route == "lane" else None)
 
 
@@ -60,6 +58,9 @@ class EpisodeRunner:
     def __init__(self, n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max_episode_length=100.0):
         import torch
         self.torch = torch
+        if controller not in ("st", "combined"):
+            # (the policy alone -- TASK EVALUATE_DDPG -- is not on the solver's path: SURVEY section 2 marks ddpg.py out of scope; removed in round 6)
+            raise ValueError("controller must be 'st' or 'combined', not %r" % (controller,))
         self.n, self.kmax, self.controller, self.policy = int(n), int(kmax), controller, policy
         self.ctx = ctx or _capi.default_context()
         self.params = _capi.Params.from_settings(Settings)
@@ -71,7 +72,7 @@ class EpisodeRunner:
         self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.d_oa = z(n, 5), z(n, dtype=torch.int32), z(n, kmax), z(n, kmax), z(n, kmax)
         self.d_path, self.d_bt, self.d_cost, self.d_speed = z(n, H, dtype=torch.int32), z(n, dtype=torch.int32), z(n), z(n)
         self.d_fine, self.d_fine_len = z(n, _capi.QP_NMAX), z(n, dtype=torch.int32)
-        self.ccfg = _capi.CombinedCfg.from_settings(Settings) if controller == "combined" else None
+        self.ccfg = _capi.CombinedCfg.from_settings(Settings, sparse_control=True) if controller == "combined" else None      # (a tick ends with a host-side status check anyway)
         self.takeovers, self.controlled = z(n), z(n)
         self.last_rl = torch.ones(n, dtype=torch.int32, device=dev)
         self.d_status = z(n, dtype=torch.int32)
@@ -89,13 +90,6 @@ class EpisodeRunner:
                                         self.d_path.data_ptr(), self.d_bt.data_ptr(), self.d_cost.data_ptr(), self.d_speed.data_ptr(), self.d_fine.data_ptr(),
                                         self.d_fine_len.data_ptr(), 0)
             cmd = self.d_speed
-        elif self.controller == "policy":
-            # the policy alone (TASK EVALUATE_DDPG: RLAgent.do_control = control.set_ego_jerk(get_control(state)), dqn.py:95-96, control.py:160-178)
-            S = Settings
-            ego4 = self.d_ego5[:, :4].contiguous()
-            jerk = self.policy(1, ego4, self.d_k, self.d_ox, self.d_ov, self.d_oa).to(torch.float64)
-            acc = torch.clamp(ego4[:, 3] + jerk * self.tick_length, S.MAX_NEGATIVE_ACCELERATION, S.MAX_POSITIVE_ACCELERATION)
-            cmd = torch.clamp(ego4[:, 2] + acc * self.tick_length, 0.0, float(S.MAX_SPEED)).contiguous()
         else:
             d = combined.decide_batch_device(ctx, self.params, self.ccfg, self.d_ego5, self.d_k, self.d_ox, self.d_ov, self.policy, self.last_rl, d_oa=self.d_oa)
             cmd = d["speed"]
@@ -144,7 +138,7 @@ def run_episodes(n, seed=0, controller="st", policy=None, ctx=None, kmax=32, max
     (combined controller only).
 
     controller: "st" = ``st.do_st_control`` every tick (TASK "ST"); "combined" = ``do_combined_control`` with ``policy``
-    (see ``combined.decide_batch_device``); "policy" = the policy's jerk alone every tick (TASK EVALUATE_DDPG)."""
+    (see ``combined.decide_batch_device``)."""
     r = EpisodeRunner(n, seed, controller, policy, ctx, kmax, max_episode_length)
     limit = r.cfg.max_ticks + 1 if max_ticks is None else min(int(max_ticks), r.cfg.max_ticks + 1)
     for tick in range(limit):

@@ -9,12 +9,13 @@ cd "$(dirname "$0")/.."
 H=$(python -c 'import rl_mpc_lanemerging_amd as p; print(p.build.source_hash())')
 rm -rf gpurun_out/ev1 gpurun_out/ev2 gpurun_out/prof_$round gpurun_out/prof_${round}d
 # pass 1: suite, smoke, the workloads without counters, profiles (kernel trace + --pmc passes + phase build), parity sweeps, episode tables, schedule
-$G --timeout 2400 -- "bash scripts/gpu_run.sh ev1 env=STMPC_TEST_ARTEFACTS=gpurun_out/ev1 tests smoke bench=--workload+control bench=--workload+combined bench=--workload+episodes prof=$round prof=${round}d+--workload+default py=scripts/lab/parity_wide.py py=scripts/lab/parity_narrow.py py=scripts/lab/combined_episodes.py+1024+gpurun_out/ev1/combined_episodes.json env=STMPC_LIB=/root/repo/variants/libstmpc_times.so py=scripts/lab/times_dump.py+gpurun_out/ev1/t.bin py=scripts/lab/times_tail.py+gpurun_out/ev1/t.bin; bash scripts/lab/world_rules.sh > gpurun_out/world_rules.txt 2>&1" 2>&1 | grep "^\[" | cut -c1-220
-# stage numbers of pass 1: 1 env, 2 tests, 3 smoke, 4-6 bench, 7-8 prof, 9-11 py, 12 env, 13-14 py
+$G --timeout 2400 -- "bash scripts/gpu_run.sh ev1 env=STMPC_TEST_ARTEFACTS=gpurun_out/ev1 tests smoke bench=--workload+control bench=--workload+combined bench=--workload+episodes prof=$round prof=${round}d+--workload+default py=scripts/lab/parity_wide.py py=scripts/lab/parity_narrow.py py=scripts/lab/combined_episodes.py+1024+gpurun_out/ev1/combined_episodes.json py=scripts/lab/crash_probe.py+2048 env=STMPC_LIB=/root/repo/variants/libstmpc_times.so py=scripts/lab/times_dump.py+gpurun_out/ev1/t.bin py=scripts/lab/times_tail.py+gpurun_out/ev1/t.bin" 2>&1 | grep "^\[" | cut -c1-220
+# stage numbers of pass 1: 1 env, 2 tests, 3 smoke, 4-6 bench, 7-8 prof, 9-12 py, 13 env, 14-15 py (timing build)
 cp $R/bench_4.json $P/bench_control.json; cp $R/bench_5.json $P/bench_combined.json; cp $R/bench_6.json $P/bench_episodes.json
-cp $R/config4_full_size.json $R/combined_episodes.json $P/; cp gpurun_out/world_rules.txt $P/world_rules.txt
+cp $R/config4_full_size.json $R/combined_episodes.json $P/
+{ echo "# row f3, pure ST controller, 2048 episodes per traffic density against the reference's rows (scripts/lab/crash_probe.py); source $H"; grep -v amdgpu.ids $R/py_12.log; } > $P/st_episodes.txt
 grep -v amdgpu.ids $R/py_9.log > $P/parity_wide.txt; grep -v amdgpu.ids $R/py_10.log > $P/parity_narrow.txt
-{ echo "# per-task schedule of one N=4096 step of the timing-instrumented build (scripts/lab/mk_times.py + times_dump.py + times_tail.py), microseconds from the first task; source $H"; grep -v amdgpu.ids $R/py_14.log; } > $P/schedule.txt
+{ echo "# per-task schedule of one N=4096 step of the timing-instrumented build (scripts/lab/mk_times.py + times_dump.py + times_tail.py), microseconds from the first task; source $H"; grep -v amdgpu.ids $R/py_15.log; } > $P/schedule.txt
 python scripts/profile_summarize.py $round $P h40a21 > /dev/null; python scripts/profile_summarize.py ${round}d $P default > /dev/null; mv $P/${round}d_summary.txt $P/${round}_default_summary.txt
 # pass 2: the solver's bench lines, now against counters of this build (measured.json)
 $G --timeout 1200 -- 'bash scripts/gpu_run.sh ev2 bench bench=--workload+default bench=--episodes+8192 bench=--episodes+16384' 2>&1 | grep "^\[" | cut -c1-220

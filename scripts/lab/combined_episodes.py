@@ -1,6 +1,5 @@
 """Row f3 with the combined controller and the reference's pretrained actors: episode statistics against the reference's reported rows
-(experiment_data/saved_data.csv: combined_low_1 / combined_medium_1 / combined_default_1 / combined_moderate_1, numbers copied as data)
-and, for the actor alone (TASK EVALUATE_DDPG: ``control.set_ego_jerk(get_control(state))`` every tick), ddpg_*1_extended.
+(experiment_data/saved_data.csv: combined_low_1 / combined_medium_1 / combined_default_1 / combined_moderate_1, numbers copied as data).
 STATISTICAL comparison: the world is a restatement of the SUMO scenario, not SUMO.  usage: combined_episodes.py [n] [out.json]"""
 import json
 import sys
@@ -18,13 +17,6 @@ REF = {   # config: (actor, interval, speed, reference row: crashed, merged, mea
     "combined_default_1": ("default1", 1.2, 7.0, dict(crashed=0.0, merged=1.0, mean_speed=9.482, max_speed=16.643, mean_abs_jerk=0.775, closest_distance=6.330, time_to_merge=28.780, percent_st=0.0349, mean_disruption=0.334, max_disruption=6.615, total_disruption=6.585, disruption_time=3.052)),
     "combined_moderate_1": ("moderate1", 1.2, 11.0, dict(crashed=0.0, merged=1.0, mean_speed=13.814, max_speed=19.521, mean_abs_jerk=0.689, closest_distance=5.883, time_to_merge=20.251, percent_st=0.0374, mean_disruption=0.352, max_disruption=5.878, total_disruption=4.516, disruption_time=1.662)),
 }
-REF_DDPG = {   # the actor alone, one evaluation per tick -- the regime it was trained in (the TimeFeature input counts ticks there)
-    "ddpg_low1_extended": ("low1", 2.4, 7.0, dict(crashed=0.0181, merged=0.9819, mean_speed=12.219, max_speed=18.344, mean_abs_jerk=0.330, closest_distance=2.882, time_to_merge=22.014, mean_disruption=0.270, max_disruption=7.802, total_disruption=3.934, disruption_time=0.514)),
-    "ddpg_medium1_extended": ("medium1", 1.8, 7.0, dict(crashed=0.0012, merged=0.9988, mean_speed=11.618, max_speed=18.061, mean_abs_jerk=0.352, closest_distance=5.288, time_to_merge=23.059, mean_disruption=0.340, max_disruption=8.274, total_disruption=5.387, disruption_time=1.401)),
-    "ddpg_default1_extended": ("default1", 1.2, 7.0, dict(crashed=0.00225, merged=0.99775, mean_speed=10.794, max_speed=16.147, mean_abs_jerk=0.353, closest_distance=4.444, time_to_merge=25.000, mean_disruption=0.358, max_disruption=8.120, total_disruption=6.039, disruption_time=1.841)),
-    "ddpg_moderate1_extended": ("moderate1", 1.2, 11.0, dict(crashed=0.00625, merged=0.99375, mean_speed=15.546, max_speed=19.857, mean_abs_jerk=0.340, closest_distance=4.313, time_to_merge=17.234, mean_disruption=0.505, max_disruption=8.418, total_disruption=5.265, disruption_time=0.606)),
-    "ddpg_fast1_extended": ("fast1", 1.2, 15.0, dict(crashed=0.00025, merged=0.99975, mean_speed=19.416, max_speed=23.492, mean_abs_jerk=0.418, closest_distance=3.773, time_to_merge=13.732, mean_disruption=0.665, max_disruption=8.760, total_disruption=4.861, disruption_time=0.553)),
-}
 
 
 def main():
@@ -41,18 +33,6 @@ def main():
         for label, kw in (("", {}), ("_no_time_feature", {"time_feature": False})):
             pol = actor.DDPGActor(act, n, ctx, pkg.Settings, dev, **kw)
             st = episodes.run_episodes(n, seed=21, controller="combined", policy=pol, ctx=ctx, kmax=16)
-            s = episodes.summary(st)
-            row["here" + label] = {k: round(s[k], 4) for k in ref if k in s}
-        row["reference"] = ref
-        report[name] = row
-        print(name, json.dumps(row), flush=True)
-    for name, (act, interval, speed, ref) in REF_DDPG.items():
-        pkg.apply_overrides(pkg.REFERENCE_DEFAULT)
-        pkg.apply_overrides(dict(BASE_TRAFFIC_INTERVAL=interval, OTHER_CAR_SPEED=speed))
-        row = {}
-        for label, kw in (("", {}), ("_no_time_feature", {"time_feature": False})):
-            pol = actor.DDPGActor(act, n, ctx, pkg.Settings, dev, **kw)
-            st = episodes.run_episodes(n, seed=21, controller="policy", policy=pol, ctx=ctx, kmax=16)
             s = episodes.summary(st)
             row["here" + label] = {k: round(s[k], 4) for k in ref if k in s}
         row["reference"] = ref

@@ -11,9 +11,17 @@ lines = ["# rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu
 steps = 13      # 2 warm-up + 10 timed + 1 statistics step
 # kernel trace
 ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+dominant = None
 if ks:
     lines.append("# --kernel-trace --stats (ns)")
     lines += [l.rstrip() for l in open(ks[0])][:12]
+    # the dominant kernel = the lattice-DP launch every step makes exactly once (the first window; a side launch of the second window runs
+    # alongside it and its duration is mostly waiting): the k_solve row with one call per step and the largest average
+    rows = [r for r in csv.DictReader(open(ks[0])) if "k_solve" in r["Name"] and int(r["Calls"]) == steps]
+    if rows:
+        r = max(rows, key=lambda r_: float(r_["AverageNs"]))
+        dominant = {"dominant_kernel": r["Name"].split("(")[0].replace("void ", ""), "dominant_kernel_calls": int(r["Calls"]),
+                    "dominant_kernel_avg_ms": float(r["AverageNs"]) / 1e6, "dominant_kernel_min_ms": float(r["MinNs"]) / 1e6, "dominant_kernel_max_ms": float(r["MaxNs"]) / 1e6}
 def pmc(n):
     out = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(src, "pmc_" + n, "**", "*counter_collection.csv"), recursive=True):
@@ -31,6 +39,15 @@ for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT"):
             lines.append("%s,%s,%d,%.1f" % (k, c, len(v), sum(v) / steps))
             tot[c] += sum(v) / steps
 meas = {}
+if dominant:
+    meas.update(dominant)
+    if workload in ("h40a21", "default"):
+        # BASELINE's HBM roofline from the trace: algorithmic bytes per launch (140 B state + 16 B action / cost / layer + 4 H of path per solve,
+        # 4096 solves) / the dominant kernel's average duration / 8 TB/s
+        Hh = 40 if workload == "h40a21" else 18
+        meas["algorithmic_bytes_per_launch"] = (156 + 4 * Hh) * 4096
+        meas["hbm_roofline_achieved_gbs"] = meas["algorithmic_bytes_per_launch"] / (dominant["dominant_kernel_avg_ms"] * 1e-3) / 1e9
+        meas["hbm_roofline_frac"] = meas["hbm_roofline_achieved_gbs"] / 8000.0
 if "FETCH_SIZE" in tot or "WRITE_SIZE" in tot:
     # FETCH_SIZE / WRITE_SIZE are in KiB?  rocprofv3 reports them in kilobytes (derived: TCC_EA0_RDREQ*64/1024 ...); gfx950 correction x2 on FETCH (MI355X_MICROARCH.md, HBM section)
     fetch_b, write_b = tot.get("FETCH_SIZE", 0.0) * 1024.0, tot.get("WRITE_SIZE", 0.0) * 1024.0
@@ -58,7 +75,7 @@ if os.path.exists(ph):
 bl = os.path.join(src, "bench_line.json")
 if os.path.exists(bl):
     try:
-        d = json.loads(open(bl).read().strip().splitlines()[-1]); lines.append("# same-run bench line: %.0f %s, %.3f ms/step, kernel_ms %.3f" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"]))
+        d = json.loads(open(bl).read().strip().splitlines()[-1]); meas["bench_line_value"] = d["value"]; meas["bench_line_ms_per_step"] = d["ms_per_step"]; meas["bench_line_kernel_ms"] = d["roofline"]["kernel_ms"]; lines.append("# same-run bench line: %.0f %s, %.3f ms/step, kernel_ms %.3f" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"]))
     except Exception: pass
 open(os.path.join(rdir, tag + "_summary.txt"), "w").write("\n".join(lines) + "\n")
 mj = os.path.join(rdir, "measured.json")

@@ -309,7 +309,7 @@ def test_gpu_sparse_control_with_no_takeover_at_all(gpu_ctx, restore_settings):
     d_ego, d_k, d_ox, d_ov = t(ego), t(np.zeros(n, np.int32)), t(np.zeros((n, K))), t(np.zeros((n, K)))
     policy = lambda step, e4, k_, x_, v_, a_: torch.full((n,), -0.5, dtype=torch.float64, device=dev)
     gpu_ctx.combined_counts(reset=True)
-    d = combined.decide_batch_device(gpu_ctx, _capi.Params.from_settings(S), _capi.CombinedCfg.from_settings(S), d_ego, d_k, d_ox, d_ov, policy, None,
+    d = combined.decide_batch_device(gpu_ctx, _capi.Params.from_settings(S), _capi.CombinedCfg.from_settings(S, sparse_control=True), d_ego, d_k, d_ox, d_ov, policy, None,
                                      torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     gpu_ctx.check_error()

@@ -2,7 +2,7 @@
 reference configures (Krauss vehicles of its "simple traffic distribution", the ego under speed mode 22 on the centre line of its lanes,
 highway vehicles that brake hard while the ego laps in -- DESIGN.md section 9) but is not SUMO.  The tests compare per-episode means with the
 reference's reported rows (experiment_data/saved_data.csv, 4000-10000 SUMO episodes each; numbers copied as data) on 1024 episodes of this
-world, with tolerances set just above what is measured (profiles/r5/world_rules.txt): the pure ST controller at its three traffic densities
+world, with tolerances set just above what is measured (profiles/r5/world_rules.txt, rule 2 / lane route: the world frozen in round 6): the pure ST controller at its three traffic densities
 (time to merge +0.7 ... +1.9 %, mean speed -1.1 ... -2.4 %, mean |jerk| -1 ... -7 %, closest distance -0.3 ... -3.3 %, no crashes), and the
 combined controller with the reference's pretrained actor on BASELINE configs[2] (ST share of ticks 2.0 % against 2.4 %)."""
 import numpy as np
