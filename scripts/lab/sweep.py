@@ -37,8 +37,8 @@ for spec in specs:
         meds.append(sorted(ms)[2])
         rows.append({"tag": tag, "seed": sd, "min_ms": min(ms), "med_ms": sorted(ms)[2], "fallback": s["fallback"], "retries": s["retries"],
                      "nodes_exact": s["nodes_exact"] / n, "nodes_bound": s["nodes_bound"] / n, "digest": dig, "same_as_first": same})
-        print("%-14s seed %5d  min %.3f med %.3f  overflow %4d (last tier %4d) retries %4d guided %4d  nodes %.0f + %.0f  %s" % (tag, sd, min(ms), sorted(ms)[2], s["fallback"], s["hbm_tier"], s["retries"],
-              s.get("guided", 0), s["nodes_bound"] / n, s["nodes_exact"] / n, "" if same else "RESULTS DIFFER"), flush=True)
+        print("%-14s seed %5d  min %.3f med %.3f  overflow %4d (last tier %4d) retries %4d guided %4d pairs %3d  nodes %.0f + %.0f  %s" % (tag, sd, min(ms), sorted(ms)[2], s["fallback"], s["hbm_tier"], s["retries"],
+              s.get("guided", 0), s.get("pairs", 0), s["nodes_bound"] / n, s["nodes_exact"] / n, "" if same else "RESULTS DIFFER"), flush=True)
     print("%-14s seed-median of medians %.3f ms  (%.0f solves/s)" % (tag, float(np.median(meds)), n / float(np.median(meds)) * 1e3), flush=True)
     del ctx
     for k_, _ in kv: os.environ.pop(k_, None)
