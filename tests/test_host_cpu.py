@@ -200,6 +200,21 @@ def test_pretrained_actors_are_package_data():
             assert "tests" not in open(os.path.join(pkgdir, f)).read(), f
 
 
+def test_design_quotes_the_measured_numbers():
+    """DESIGN.md section 5 does not retype measured numbers: its figures block is generated from profiles/r6/measured.json and the committed bench line
+    (scripts/design_numbers.py), and must equal what those files say."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("design_numbers", os.path.join(REPO, "scripts", "design_numbers.py"))
+    dn = importlib.util.module_from_spec(spec); spec.loader.exec_module(dn)
+    text = open(os.path.join(REPO, "DESIGN.md")).read()
+    assert dn.BEGIN in text and dn.END in text
+    cur = text[text.index(dn.BEGIN):text.index(dn.END) + len(dn.END)]
+    assert cur == dn.block("r6"), "run scripts/design_numbers.py r6"
+    import json
+    m = json.load(open(os.path.join(REPO, "profiles", "r6", "measured.json")))["h40a21"]
+    assert ("%.3f ms" % m["dominant_kernel_avg_ms"]) in cur and ("%.2e" % m["hbm_roofline_frac"]) in cur
+
+
 def test_synth_generator_is_seeded_and_ordered():
     from rl_mpc_lanemerging_amd import synth
     a = synth.generate_states(64, seed=3)
